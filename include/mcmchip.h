@@ -1,0 +1,232 @@
+/*
+ * mcmchip.h -- C-ABI of libmcmchip.so, the MI355X (gfx950) implementation of the
+ * sampler hot path of the R package `mcmc` (reference: /root/reference/package/mcmc).
+ *
+ * This is the drop-in boundary.  Every entry point takes plain pointers and
+ * sizes (no R types, no torch types).  The reference's `.Call`/`.C` natives
+ * (src/init.c:7-20, src/mcmc.h:8-18) would forward to these when the `obj`
+ * argument is a log-density *descriptor* instead of an R closure; see
+ * INTEGRATION.md for the binding a maintainer adds to src/metrop.c etc.
+ *
+ * Conventions
+ *   - all floating point is IEEE binary64 ("double").
+ *   - every function returns MCMCHIP_OK (0) or an error code; the message
+ *     (same wording as the reference's error() call where one exists) is
+ *     retrievable with mcmchip_last_error() from the same thread.
+ *   - `device_ptrs == 0`: data pointers are host memory, the library stages
+ *     them through HBM.  `device_ptrs == 1`: data pointers are device (HIP)
+ *     memory on the current device, nothing crosses PCIe.
+ *   - inputs are never modified (reference: metrop.c:67-70 duplicates
+ *     `initial`); outputs are caller-allocated.
+ *   - batched extension: the reference runs ONE chain per call; here a call
+ *     advances `nchain` independent chains in lockstep.  With nchain == 1 the
+ *     output arrays have exactly the reference's C-side shapes.
+ */
+#ifndef MCMCHIP_H
+#define MCMCHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMCHIP_OK       0
+#define MCMCHIP_EINVAL   1  /* bad argument (reference: the error() calls in metrop.c:35-65, temper.c:21-95) */
+#define MCMCHIP_EDOMAIN  2  /* log density -Inf at initial state, or +Inf/NaN anywhere (metrop.c:196-197,317-320) */
+#define MCMCHIP_EHIP     3  /* HIP runtime error */
+#define MCMCHIP_ECAP     4  /* caller-provided output capacity too small (initseq) */
+
+/* ------------------------------------------------------------------ */
+/* log unnormalised density descriptors (replace the R closure `func1`,
+ * metrop.c:303-323 / temper.c:955-975)                                 */
+/* ------------------------------------------------------------------ */
+enum {
+    /* vignettes/demo.Rnw:59-65: eta = X beta;
+     *   logp = eta<0 ? eta-log1p(exp(eta)) : -log1p(exp(-eta))
+     *   logq = eta<0 ? -log1p(exp(eta))    : -eta-log1p(exp(-eta))
+     *   sum(logp[y==1]) + sum(logq[y==0]) - prior_c*sum(beta^2)   (demo: prior_c = 1/8) */
+    MCMCHIP_T_LOGISTIC = 1,
+    /* tests/logit.R:40-48: p = exp(eta)/(1+exp(eta)); sum(log(p[y==1])) + sum(log(1-p[y==0])) - prior_c*sum(beta^2) */
+    MCMCHIP_T_LOGISTIC_NAIVE = 2,
+    /* -0.5 (x-mu)' P (x-mu);  par = mu[d], P[d*d] (row-major, symmetric precision matrix) */
+    MCMCHIP_T_MVNORM = 3,
+    /* log sum_k exp(a_k - b_k |x-mu_k|^2);  par = K, then K records {a_k, b_k, mu_k[d]} */
+    MCMCHIP_T_NORMMIX = 4,
+    /* tests/accept-batch.R:8, devel/bug/foo.Rout:28: all(x>=0) && sum(x)<=1 ? par[0] : -Inf */
+    MCMCHIP_T_SIMPLEX = 5,
+    /* tests/circle.R:11-16: fred = 1-sum(x^2); fred>0 ? log(fred) : -Inf */
+    MCMCHIP_T_BALL = 6,
+    /* tests/temp-par-witch.R:24-40 (temper only, state = (i, theta)): par = bnd[k]
+     *   any(|theta|>1) -> -Inf; all(|theta|>bnd_i) -> -(d+1)log2 - d log(1-bnd_i);
+     *   else -(d+1)log2 - log1p(-(1-bnd_i)^d) */
+    MCMCHIP_T_WITCH = 7,
+    /* temper only: h(i,x) = beta_i * normmix(x);  par = k, beta[k], then a NORMMIX par block */
+    MCMCHIP_T_TEMPERED_NORMMIX = 8
+};
+
+typedef struct mcmchip_target_desc {
+    int32_t kind;
+    int32_t d;          /* dimension of the state (of theta for temper targets) */
+    int64_t n;          /* observations (logistic kinds), else 0 */
+    const double *x;    /* n x d, row-major (logistic kinds) */
+    const double *y;    /* n, values 0/1 (logistic kinds) */
+    double prior_c;     /* logistic kinds: subtract prior_c * sum(beta^2) */
+    const double *par;  /* kind-specific parameter block, see enum */
+    int64_t npar;
+} mcmchip_target_desc;
+
+typedef struct mcmchip_target mcmchip_target; /* opaque: descriptor resident in HBM */
+
+/* ------------------------------------------------------------------ */
+/* proposal scale (metrop.c:333-404, temper.c:915-953,990-1026)         */
+/* ------------------------------------------------------------------ */
+enum {
+    MCMCHIP_SCALE_CONSTANT = 1,  /* 1 double */
+    MCMCHIP_SCALE_DIAGONAL = 2,  /* d doubles */
+    MCMCHIP_SCALE_FULL     = 3,  /* d*d doubles, column-major as R stores it; p = x + S z accumulated column by column (metrop.c:391-399) */
+    MCMCHIP_SCALE_LIST     = 8   /* temper only, OR-ed with one of the above: k consecutive blocks, one per component (temper.c:998-999) */
+};
+
+/* output functional g(x) (metrop.c:416-548) */
+enum {
+    MCMCHIP_OUT_IDENTITY = 0,  /* func2 == NULL */
+    MCMCHIP_OUT_INDEX    = 1,  /* logical / +-index vector, already resolved to a 0/1 mask of length d (metrop.c:435-497) */
+    MCMCHIP_OUT_MOMENTS2 = 2   /* c(x, x^2), the vignette's outfun (vignettes/demo.Rnw:264) */
+};
+
+/* random stream */
+enum {
+    /* parity mode: normals z[chain][iter][d], uniforms u[chain][iter]; the uniform of an
+     * iteration is read from its slot only when the reference would draw one (metrop.c:226-233) */
+    MCMCHIP_RNG_INJECTED = 1,
+    /* device mode: counter-based Philox4x32-10 keyed by (seed), counter = (iteration, global chain id, draw) */
+    MCMCHIP_RNG_PHILOX = 2
+};
+
+enum { MCMCHIP_PATH_AUTO = 0, MCMCHIP_PATH_STREAM = 1, MCMCHIP_PATH_MFMA = 2 };
+
+/* ------------------------------------------------------------------ */
+/* metrop  -- replaces SEXP metrop(func1, initial, nbatch, blen, nspac,
+ * scale, func2, debug, rho1, rho2)  (src/mcmc.h:8-9, metrop.c:19-301)  */
+/* ------------------------------------------------------------------ */
+typedef struct mcmchip_metrop_args {
+    int64_t nchain;
+    int32_t nbatch, blen, nspac;     /* all > 0 (metrop.c:60-65) */
+    const double *initial;           /* nchain x d, chain-major; all finite (metrop.c:72-73) */
+    int32_t scale_kind;
+    const double *scale;
+    int32_t out_kind;
+    const int32_t *out_index;        /* d entries 0/1 when out_kind == INDEX */
+    int32_t rng_mode;
+    const double *z;                 /* INJECTED: nchain x niter x d */
+    const double *u;                 /* INJECTED: nchain x niter */
+    uint64_t seed;                   /* PHILOX key */
+    uint64_t chain_offset;           /* PHILOX: global id of local chain 0 (results independent of sharding) */
+    uint64_t iter_offset;            /* PHILOX: iterations already done (restart: split runs == one long run, tests/saveseed.R) */
+    int32_t debug;                   /* fill the debug trace (metrop.c:129-180,237-257) */
+    int32_t device_ptrs;
+    int32_t path;                    /* MCMCHIP_PATH_* */
+} mcmchip_metrop_args;
+
+typedef struct mcmchip_metrop_out {
+    double *accept;         /* nchain                      (metrop.c:289) */
+    double *batch;          /* nchain x nbatch x nout : batch[(c*nbatch+ib)*nout+j]; per chain this is the
+                               reference's dim_out x nbatch column-major `path` (metrop.c:103,279-280) */
+    double *final;          /* nchain x d                  (metrop.c:291-297) */
+    double *accept_batch;   /* nchain x nbatch             (metrop.c:282-283) */
+    /* debug trace, NULL unless args.debug; iteration index l = ispac + nspac*(jbatch + blen*ibatch) (metrop.c:238) */
+    double *current;        /* nchain x niter x d : state BEFORE the update */
+    double *proposal;       /* nchain x niter x d */
+    double *z;              /* nchain x niter x d */
+    double *log_green;      /* nchain x niter : lud(proposal) - lud(current), may be -Inf */
+    double *u;              /* nchain x niter : uniform drawn, NaN where the reference records NA (metrop.c:252-255) */
+    int32_t *debug_accept;  /* nchain x niter */
+    uint64_t iter_offset_out; /* args.iter_offset + nbatch*blen*nspac */
+    int32_t nout;           /* dim of g(x) */
+    int32_t path_used;
+} mcmchip_metrop_out;
+
+/* ------------------------------------------------------------------ */
+/* temper -- replaces SEXP temper(func1, initial, neighbors, nbatch, blen,
+ * nspac, scale, func2, debug, parallel, rho1, rho2) (mcmc.h:10-12,
+ * temper.c:17-913).  `nens` independent ensembles advance in lockstep.   */
+/* ------------------------------------------------------------------ */
+typedef struct mcmchip_temper_args {
+    int64_t nens;
+    int32_t ncomp;                   /* k >= 2 (temper.c:35-37) */
+    int32_t parallel;                /* 1: parallel tempering, state k x p; 0: serial, state (i, x) */
+    int32_t nbatch, blen, nspac;
+    const int32_t *neighbors;        /* k x k, 0/1, symmetric (temper.c:29-41) */
+    const double *initial;           /* parallel: nens x (k x p column-major, state[i + k*j], temper.c:563);
+                                        serial:   nens x (1+p) = (i, x) with 1 <= i <= k (temper.c:55-63) */
+    int32_t scale_kind;              /* CONSTANT | DIAGONAL | FULL, optionally | LIST */
+    const double *scale;
+    int32_t rng_mode;
+    /* INJECTED: unif[ens][iter][4] = {u_which, u_choose(1), u_choose2, u_hastings} slots, each read
+     * only when the reference draws it (temper.c:537,553,585,649,681-682,753,791,821);
+     * norm[ens][iter][p] */
+    const double *unif;
+    const double *norm;
+    uint64_t seed, ens_offset, iter_offset;
+    int32_t device_ptrs;
+} mcmchip_temper_args;
+
+typedef struct mcmchip_temper_out {
+    double *batch;     /* parallel: nens x (nbatch x k x p), per ensemble batch[kb + nbatch*(i + k*j)] (temper.c:871-875);
+                          serial:   nens x (nbatch x p),     per ensemble batch[kb + nbatch*j]       (temper.c:877-879) */
+    double *ibatch;    /* serial only: nens x (nbatch x k), ibatch[kb + nbatch*i] (temper.c:881-886); may be NULL if parallel */
+    double *acceptx;   /* nens x k ; 0/0 = NaN for a component never tried (temper.c:889-890) */
+    double *accepti;   /* nens x (k x k column-major); NaN (reference: NA_REAL) for non-neighbours (temper.c:892-897) */
+    double *final;     /* same shape as initial */
+    uint64_t iter_offset_out;
+} mcmchip_temper_out;
+
+/* ------------------------------------------------------------------ */
+/* library / target lifetime                                            */
+/* ------------------------------------------------------------------ */
+int mcmchip_init(int device);                 /* select device, create streams; idempotent */
+const char *mcmchip_last_error(void);
+const char *mcmchip_version(void);
+
+/* copy a descriptor into HBM (desc pointers are host memory unless desc_device_ptrs) and
+ * pre-tile X for the fp64 MFMA path; replaces capturing `func1`/`rho1` (metrop.c:35-38) */
+int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs, mcmchip_target **out);
+void mcmchip_target_destroy(mcmchip_target *t);
+
+/* evaluate the log density of `nchain` states (chain-major nchain x d; for temper kinds (1+d): (i, theta)).
+ * replaces logh() (metrop.c:303-323); -Inf allowed, +Inf/NaN are reported in the values, not as errors */
+int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchain, int path,
+                    int device_ptrs, double *out);
+
+int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *args, mcmchip_metrop_out *out);
+
+int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *args, mcmchip_temper_out *out);
+
+/* initseq -- replaces SEXP initseq(SEXP x) (mcmc.h:14, initseq.c:7-128), batched over `ncol`
+ * series stored column-major x[t + len*c].  Input is used as given: the caller centres it
+ * (R/initseq.R:4).  Output vectors have data-dependent length n_out[c] <= len/2
+ * (initseq.c:24-47); caller passes capacity `cap` per column and arrays ncol x cap.
+ * Returns MCMCHIP_ECAP (n_out filled with the needed lengths) if cap is too small. */
+int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs,
+                    int64_t cap, int64_t *n_out,
+                    double *gamma0, double *Gamma_pos, double *Gamma_dec, double *Gamma_con,
+                    double *var_pos, double *var_dec, double *var_con);
+
+/* olbm -- replaces void olbm(double *x, int *nin, int *pin, int *lin, double *mean,
+ * double *var, int *nocalcin) (mcmc.h:16-17, olbm.c:22-78).  x is n x p column-major.
+ * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned. */
+int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
+                 int32_t nocalc, int device_ptrs);
+
+/* timing of the most recent call's dominant kernel, measured with HIP events on the
+ * library's own stream (bench.py roofline): average ms per launch and launch count */
+int mcmchip_last_kernel_time(double *avg_ms, int64_t *launches, char *name, int name_cap);
+
+/* synchronise the library's stream */
+int mcmchip_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMCHIP_H */

@@ -1,0 +1,757 @@
+/*
+ * oracle.c -- TEST INFRASTRUCTURE.  A plain-C, single-thread-per-chain CPU restatement of the
+ * reference's sampler hot path, used ONLY as the checker by tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.  Nothing under mcmc_amd/ links, imports or calls it.
+ *
+ * Each function cites the reference lines (under /root/reference/package/mcmc/) it follows.
+ * The arithmetic order is the reference's: proposals are x + s*z with separately rounded
+ * multiply and add (compiled with -ffp-contract=off), full-matrix scale accumulates column
+ * by column (metrop.c:391-399), log densities are evaluated sequentially, R's sum() is
+ * mirrored with long double accumulators (R accumulates sum() in LDOUBLE).
+ *
+ * Pinning (tests/test_oracle_golden.py): the oracle, driven by the R RNG emulation in
+ * rrng.c, reproduces the numbers printed in the reference's own transcripts:
+ * devel/bug/foo.Rout, tests/accept-batch.Rout.save, tests/circle.Rout.save,
+ * tests/logit.Rout.save (incl. the olbm matrix), tests/temp-par-witch.Rout.save,
+ * tests/temp-ser-witch.Rout.save; initseq is pinned by the identities of tests/initseq.R.
+ * The reference C itself is NOT built here: it needs R's headers (R.h, Rinternals.h,
+ * Rmath.h), which the image lacks, so it counts as unbuildable.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/mcmchip.h"
+#include "oracle.h"
+
+/* ------------------------------------------------------------------ */
+/* Philox4x32-10 + draw maps (must agree with mcmc_amd/csrc/philox.h)   */
+/* ------------------------------------------------------------------ */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+static double u53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+/* two uniforms in (0,1) for (sampler tag, chain, iteration, block) */
+static void philox_u2(uint64_t seed, uint32_t tag, uint64_t chain, uint64_t iter, uint32_t block,
+                      double *ua, double *ub)
+{
+    uint32_t c[4] = {(uint32_t)iter, (uint32_t)(iter >> 32), (uint32_t)chain, block};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ tag);
+    *ua = u53(c[0], c[1]);
+    *ub = u53(c[2], c[3]);
+}
+
+/* Box-Muller pair */
+static void philox_n2(uint64_t seed, uint32_t tag, uint64_t chain, uint64_t iter, uint32_t block,
+                      double *za, double *zb)
+{
+    double u1, u2;
+    philox_u2(seed, tag, chain, iter, block, &u1, &u2);
+    double r = sqrt(-2.0 * log(u1));
+    double t = 6.283185307179586 * u2;
+    *za = r * cos(t);
+    *zb = r * sin(t);
+}
+
+#define PHILOX_TAG_METROP 0u
+#define PHILOX_TAG_TEMPER 0x54454d50u
+#define PHILOX_BLOCK_UNIF 0xFFFFFFFFu
+
+void orc_philox_normals(uint64_t seed, uint64_t chain, uint64_t iter, int d, double *z)
+{
+    for (int j = 0; j < d; j += 2) {
+        double a, b;
+        philox_n2(seed, PHILOX_TAG_METROP, chain, iter, (uint32_t)(j / 2), &a, &b);
+        z[j] = a;
+        if (j + 1 < d) z[j + 1] = b;
+    }
+}
+
+double orc_philox_uniform(uint64_t seed, uint64_t chain, uint64_t iter)
+{
+    double a, b;
+    philox_u2(seed, PHILOX_TAG_METROP, chain, iter, PHILOX_BLOCK_UNIF, &a, &b);
+    return a;
+}
+
+/* ------------------------------------------------------------------ */
+/* log unnormalised densities                                           */
+/* ------------------------------------------------------------------ */
+
+static double normmix_eval(const double *par, int d, const double *x)
+{
+    int K = (int)par[0];
+    const double *rec = par + 1;
+    double m = -INFINITY;
+    double v[K > 0 ? K : 1];
+    for (int k = 0; k < K; k++) {
+        const double *r = rec + (size_t)k * (2 + d);
+        double s = 0.0;
+        for (int j = 0; j < d; j++) {
+            double t = x[j] - r[2 + j];
+            s += t * t;
+        }
+        v[k] = r[0] - r[1] * s;
+        if (v[k] > m) m = v[k];
+    }
+    if (m == -INFINITY) return -INFINITY;
+    double acc = 0.0;
+    for (int k = 0; k < K; k++) acc += exp(v[k] - m);
+    return m + log(acc);
+}
+
+/* metrop targets: state = x[d] */
+double orc_lud(const mcmchip_target_desc *t, const double *b)
+{
+    int d = t->d;
+    switch (t->kind) {
+    case MCMCHIP_T_LOGISTIC: {
+        /* vignettes/demo.Rnw:59-65 */
+        long double lp = 0.0L, lq = 0.0L, ss = 0.0L;
+        for (int64_t i = 0; i < t->n; i++) {
+            const double *xi = t->x + (size_t)i * d;
+            double eta = 0.0;
+            for (int j = 0; j < d; j++) eta += xi[j] * b[j];
+            if (t->y[i] == 1.0)
+                lp += (eta < 0) ? eta - log1p(exp(eta)) : -log1p(exp(-eta));
+            else
+                lq += (eta < 0) ? -log1p(exp(eta)) : -eta - log1p(exp(-eta));
+        }
+        for (int j = 0; j < d; j++) ss += b[j] * b[j];
+        double logl = (double)lp + (double)lq;
+        return logl - (double)ss * t->prior_c;
+    }
+    case MCMCHIP_T_LOGISTIC_NAIVE: {
+        /* tests/logit.R:40-48 */
+        long double lp = 0.0L, lq = 0.0L, ss = 0.0L;
+        for (int64_t i = 0; i < t->n; i++) {
+            const double *xi = t->x + (size_t)i * d;
+            double eta = 0.0;
+            for (int j = 0; j < d; j++) eta += xi[j] * b[j];
+            double e = exp(eta);
+            double p = e / (1.0 + e);
+            if (t->y[i] == 1.0) lp += log(p);
+            else lq += log(1.0 - p);
+        }
+        double logl = (double)lp + (double)lq;
+        if (t->prior_c == 0.0) return logl;
+        for (int j = 0; j < d; j++) ss += b[j] * b[j];
+        return logl - (double)ss * t->prior_c;
+    }
+    case MCMCHIP_T_MVNORM: {
+        const double *mu = t->par, *P = t->par + d;
+        double q = 0.0;
+        for (int i = 0; i < d; i++) {
+            double ti = 0.0;
+            for (int j = 0; j < d; j++) ti += P[(size_t)i * d + j] * (b[j] - mu[j]);
+            q += (b[i] - mu[i]) * ti;
+        }
+        return -0.5 * q;
+    }
+    case MCMCHIP_T_NORMMIX:
+        return normmix_eval(t->par, d, b);
+    case MCMCHIP_T_SIMPLEX: {
+        /* tests/accept-batch.R:8 ; devel/bug/foo.Rout:28 */
+        long double s = 0.0L;
+        for (int j = 0; j < d; j++) {
+            if (!(b[j] >= 0)) return -INFINITY;
+            s += b[j];
+        }
+        return ((double)s <= 1.0) ? t->par[0] : -INFINITY;
+    }
+    case MCMCHIP_T_BALL: {
+        /* tests/circle.R:11-16 */
+        long double s = 0.0L;
+        for (int j = 0; j < d; j++) s += b[j] * b[j];
+        double fred = 1.0 - (double)s;
+        return (fred > 0) ? log(fred) : -INFINITY;
+    }
+    default:
+        return NAN;
+    }
+}
+
+/* temper targets: state = (i, theta[d]), i is 1-based */
+double orc_lud_temper(const mcmchip_target_desc *t, int i, const double *th)
+{
+    int d = t->d;
+    switch (t->kind) {
+    case MCMCHIP_T_WITCH: {
+        /* tests/temp-par-witch.R:24-40 */
+        for (int j = 0; j < d; j++)
+            if (fabs(th[j]) > 1.0) return -INFINITY;
+        double bnd = t->par[i - 1];
+        int all = 1;
+        for (int j = 0; j < d; j++)
+            if (!(fabs(th[j]) > bnd)) all = 0;
+        if (all) return -(d + 1) * log(2) - d * log(1 - bnd);
+        return -(d + 1) * log(2) - log1p(-pow(1 - bnd, d));
+    }
+    case MCMCHIP_T_TEMPERED_NORMMIX: {
+        int k = (int)t->par[0];
+        double beta = t->par[i];
+        return beta * normmix_eval(t->par + 1 + k, d, th);
+    }
+    default:
+        return NAN;
+    }
+}
+
+void orc_logdens(const mcmchip_target_desc *t, const double *states, int64_t nchain, double *out)
+{
+    int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX);
+    for (int64_t c = 0; c < nchain; c++) {
+        if (temper_kind) {
+            const double *s = states + (size_t)c * (t->d + 1);
+            out[c] = orc_lud_temper(t, (int)s[0], s + 1);
+        } else {
+            out[c] = orc_lud(t, states + (size_t)c * t->d);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* proposal arithmetic (metrop.c:367-404, temper.c:990-1026)            */
+/* ------------------------------------------------------------------ */
+static void propose_from(const double *x, double *y, const double *z, int d, int scale_kind,
+                         const double *s)
+{
+    switch (scale_kind) {
+    case MCMCHIP_SCALE_CONSTANT:
+        for (int j = 0; j < d; j++) y[j] = x[j] + s[0] * z[j];
+        break;
+    case MCMCHIP_SCALE_DIAGONAL:
+        for (int j = 0; j < d; j++) y[j] = x[j] + s[j] * z[j];
+        break;
+    default: /* FULL: column i of S times z[i], added in turn */
+        for (int j = 0; j < d; j++) y[j] = x[j];
+        for (int i = 0, k = 0; i < d; i++) {
+            double zi = z[i];
+            for (int j = 0; j < d; j++) y[j] += s[k++] * zi;
+        }
+    }
+}
+
+static int scale_len(int kind, int d)
+{
+    switch (kind & 7) {
+    case MCMCHIP_SCALE_CONSTANT: return 1;
+    case MCMCHIP_SCALE_DIAGONAL: return d;
+    case MCMCHIP_SCALE_FULL: return d * d;
+    default: return -1;
+    }
+}
+
+static int fail(char *err, int errlen, int code, const char *msg)
+{
+    if (err && errlen > 0) snprintf(err, (size_t)errlen, "%s", msg);
+    return code;
+}
+
+static int out_dim(int out_kind, const int32_t *idx, int d)
+{
+    if (out_kind == MCMCHIP_OUT_IDENTITY) return d;
+    if (out_kind == MCMCHIP_OUT_MOMENTS2) return 2 * d;
+    int n = 0;
+    for (int j = 0; j < d; j++) n += idx[j] != 0;
+    return n;
+}
+
+static void apply_out(int out_kind, const int32_t *idx, int d, const double *x, double *g)
+{
+    if (out_kind == MCMCHIP_OUT_IDENTITY) {
+        for (int j = 0; j < d; j++) g[j] = x[j];
+    } else if (out_kind == MCMCHIP_OUT_MOMENTS2) {
+        for (int j = 0; j < d; j++) { g[j] = x[j]; g[d + j] = x[j] * x[j]; }
+    } else {
+        for (int j = 0, k = 0; j < d; j++)
+            if (idx[j]) g[k++] = x[j];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* metrop: one chain (metrop.c:193-300)            */
+/* ------------------------------------------------------------------ */
+static int metrop_chain(const mcmchip_target_desc *t, const mcmchip_metrop_args *a,
+                        mcmchip_metrop_out *o, int64_t c, orc_rstream *rs, char *err, int errlen)
+{
+    int d = t->d;
+    int nout = out_dim(a->out_kind, a->out_index, d);
+    int64_t niter = (int64_t)a->nbatch * a->blen * a->nspac;
+    double x[d], y[d], z[d], g[nout], buf[nout];
+    for (int j = 0; j < d; j++) {
+        x[j] = a->initial[(size_t)c * d + j];
+        if (!isfinite(x[j])) return fail(err, errlen, MCMCHIP_EINVAL, "all elements of \"state\" must be finite");
+    }
+    double cur = orc_lud(t, x);
+    if (cur == -INFINITY) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density -Inf at initial state");
+    if (cur == INFINITY) return fail(err, errlen, MCMCHIP_EDOMAIN, "logh: func returned +Inf");
+    if (isnan(cur)) return fail(err, errlen, MCMCHIP_EDOMAIN, "logh: func returned NA or NaN");
+
+    double acc = 0.0, tries = 0.0;
+    for (int ib = 0; ib < a->nbatch; ib++) {
+        double acc_b = 0.0, tries_b = 0.0;
+        for (int j = 0; j < nout; j++) buf[j] = 0.0;
+        for (int jb = 0; jb < a->blen; jb++) {
+            for (int is = 0; is < a->nspac; is++) {
+                int64_t l = is + (int64_t)a->nspac * (jb + (int64_t)a->blen * ib);
+                /* d normals, always, in index order (metrop.c:377-378) */
+                if (a->rng_mode == MCMCHIP_RNG_INJECTED) {
+                    for (int j = 0; j < d; j++) z[j] = a->z[((size_t)c * niter + l) * d + j];
+                } else if (a->rng_mode == MCMCHIP_RNG_PHILOX) {
+                    orc_philox_normals(a->seed, a->chain_offset + c, a->iter_offset + l, d, z);
+                } else {
+                    for (int j = 0; j < d; j++) z[j] = orc_r_norm(rs);
+                }
+                propose_from(x, y, z, d, a->scale_kind, a->scale);
+                double ly = orc_lud(t, y);
+                if (ly == INFINITY) return fail(err, errlen, MCMCHIP_EDOMAIN, "logh: func returned +Inf");
+                if (isnan(ly)) return fail(err, errlen, MCMCHIP_EDOMAIN, "logh: func returned NA or NaN");
+                int accept = 0;
+                double u = NAN; /* NA in the reference's trace */
+                if (ly != -INFINITY) {              /* metrop.c:226: no uniform for -Inf */
+                    if (ly > cur) {
+                        accept = 1;                 /* metrop.c:227-228: no uniform */
+                    } else {
+                        double green = exp(ly - cur);
+                        if (a->rng_mode == MCMCHIP_RNG_INJECTED) u = a->u[(size_t)c * niter + l];
+                        else if (a->rng_mode == MCMCHIP_RNG_PHILOX)
+                            u = orc_philox_uniform(a->seed, a->chain_offset + c, a->iter_offset + l);
+                        else u = orc_r_unif(rs);
+                        accept = u < green;         /* metrop.c:230-233 */
+                    }
+                }
+                if (a->debug && o->current) {
+                    size_t base = ((size_t)c * niter + l) * d;
+                    for (int j = 0; j < d; j++) {
+                        o->current[base + j] = x[j];
+                        o->proposal[base + j] = y[j];
+                        o->z[base + j] = z[j];
+                    }
+                    o->log_green[(size_t)c * niter + l] = ly - cur;
+                    o->u[(size_t)c * niter + l] = u;
+                    o->debug_accept[(size_t)c * niter + l] = accept;
+                }
+                if (accept) {
+                    for (int j = 0; j < d; j++) x[j] = y[j];
+                    cur = ly;
+                    acc++; acc_b++;
+                }
+                tries++; tries_b++;
+            }
+            apply_out(a->out_kind, a->out_index, d, x, g);
+            for (int j = 0; j < nout; j++) buf[j] += g[j];
+        }
+        for (int j = 0; j < nout; j++)
+            o->batch[((size_t)c * a->nbatch + ib) * nout + j] = buf[j] / a->blen;
+        o->accept_batch[(size_t)c * a->nbatch + ib] = acc_b / tries_b;
+    }
+    o->accept[c] = acc / tries;
+    for (int j = 0; j < d; j++) o->final[(size_t)c * d + j] = x[j];
+    return MCMCHIP_OK;
+}
+
+static int metrop_check(const mcmchip_target_desc *t, const mcmchip_metrop_args *a, char *err, int errlen)
+{
+    if (a->nbatch <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"nbatch\" must be positive");
+    if (a->blen <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"blen\" must be positive");
+    if (a->nspac <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"nspac\" must be positive");
+    if (scale_len(a->scale_kind, t->d) < 0 || (a->scale_kind & MCMCHIP_SCALE_LIST))
+        return fail(err, errlen, MCMCHIP_EINVAL, "length of \"scale\" vector not d or 1");
+    return MCMCHIP_OK;
+}
+
+int orc_metrop(const mcmchip_target_desc *t, const mcmchip_metrop_args *a, mcmchip_metrop_out *o,
+               orc_rstream *rs, int nthreads, char *err, int errlen)
+{
+    int rc = metrop_check(t, a, err, errlen);
+    if (rc) return rc;
+    o->nout = out_dim(a->out_kind, a->out_index, t->d);
+    o->iter_offset_out = a->iter_offset + (uint64_t)a->nbatch * a->blen * a->nspac;
+    o->path_used = -1;
+    if (a->rng_mode == ORC_RNG_RSTREAM || nthreads <= 1) {
+        for (int64_t c = 0; c < a->nchain; c++) {
+            rc = metrop_chain(t, a, o, c, rs, err, errlen);
+            if (rc) return rc;
+        }
+        return MCMCHIP_OK;
+    }
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t c = 0; c < a->nchain; c++) {
+        char e[256];
+        int r = metrop_chain(t, a, o, c, NULL, e, sizeof e);
+        if (r) {
+#pragma omp critical
+            { if (!bad) { bad = r; if (err) snprintf(err, (size_t)errlen, "%s", e); } }
+        }
+    }
+    return bad;
+}
+
+/* ------------------------------------------------------------------ */
+/* temper: one ensemble (temper.c:476-899)          */
+/* ------------------------------------------------------------------ */
+enum { SLOT_WHICH = 0, SLOT_CHOOSE1 = 1, SLOT_CHOOSE2 = 2, SLOT_HAST = 3 };
+
+typedef struct {
+    const mcmchip_temper_args *a;
+    orc_rstream *rs;
+    int64_t e, niter;
+    int p;
+} tdraw;
+
+static double t_unif(const tdraw *s, int64_t it, int slot)
+{
+    const mcmchip_temper_args *a = s->a;
+    if (a->rng_mode == MCMCHIP_RNG_INJECTED) return a->unif[((size_t)s->e * s->niter + it) * 4 + slot];
+    if (a->rng_mode == MCMCHIP_RNG_PHILOX) {
+        double ua, ub;
+        philox_u2(a->seed, PHILOX_TAG_TEMPER, a->ens_offset + s->e, a->iter_offset + it,
+                  (uint32_t)(slot >> 1), &ua, &ub);
+        return (slot & 1) ? ub : ua;
+    }
+    return orc_r_unif(s->rs);
+}
+
+static void t_norm(const tdraw *s, int64_t it, double *z)
+{
+    const mcmchip_temper_args *a = s->a;
+    int p = s->p;
+    if (a->rng_mode == MCMCHIP_RNG_INJECTED) {
+        for (int j = 0; j < p; j++) z[j] = a->norm[((size_t)s->e * s->niter + it) * p + j];
+    } else if (a->rng_mode == MCMCHIP_RNG_PHILOX) {
+        for (int j = 0; j < p; j += 2) {
+            double za, zb;
+            philox_n2(a->seed, PHILOX_TAG_TEMPER, a->ens_offset + s->e, a->iter_offset + it,
+                      (uint32_t)(2 + j / 2), &za, &zb);
+            z[j] = za;
+            if (j + 1 < p) z[j + 1] = zb;
+        }
+    } else {
+        for (int j = 0; j < p; j++) z[j] = orc_r_norm(s->rs);
+    }
+}
+
+/* min(trunc(m*u)+1, m), 1-based (temper.c:555-556) */
+static int pick(double u, int m)
+{
+    int i = (int)trunc(m * u) + 1;
+    if (i > m) i--;
+    return i;
+}
+
+/* oracle-side output functionals of the witch tests (R closures in the reference's tests) */
+static int t_nout(const mcmchip_target_desc *t, const mcmchip_temper_args *a, int out_kind)
+{
+    int k = a->ncomp, p = t->d;
+    switch (out_kind) {
+    case ORC_TOUT_NONE: return a->parallel ? k * p : p;
+    case ORC_TOUT_WITCH_PAR: return k;       /* temp-par-witch.R: as.numeric(all(|theta_i| > bnd_i)) per component */
+    case ORC_TOUT_WITCH_SER: return 2 * k;   /* temp-ser-witch.R: c(bar, baz) */
+    default: return -1;
+    }
+}
+
+static void t_out(const mcmchip_target_desc *t, const mcmchip_temper_args *a, int out_kind,
+                  const double *state, double *g)
+{
+    int k = a->ncomp, p = t->d;
+    if (out_kind == ORC_TOUT_NONE) {
+        if (a->parallel) for (int i = 0; i < k * p; i++) g[i] = state[i];
+        else for (int i = 0; i < p; i++) g[i] = state[i + 1];
+    } else if (out_kind == ORC_TOUT_WITCH_PAR) {
+        for (int i = 0; i < k; i++) {
+            int all = 1;
+            for (int j = 0; j < p; j++)
+                if (!(fabs(state[i + k * j]) - t->par[i] > 0)) all = 0;
+            g[i] = all;
+        }
+    } else {
+        int ic = (int)state[0];
+        int all = 1;
+        for (int j = 0; j < p; j++)
+            if (!(fabs(state[1 + j]) > t->par[ic - 1])) all = 0;
+        for (int i = 0; i < 2 * k; i++) g[i] = 0.0;
+        g[ic - 1] = all;
+        g[k + ic - 1] = 1.0;
+    }
+}
+
+static const double *t_scale(const mcmchip_temper_args *a, int p, int comp /*1-based*/)
+{
+    if (a->scale_kind & MCMCHIP_SCALE_LIST) return a->scale + (size_t)(comp - 1) * scale_len(a->scale_kind, p);
+    return a->scale;
+}
+
+static int temper_ens(const mcmchip_target_desc *t, const mcmchip_temper_args *a, mcmchip_temper_out *o,
+                      int64_t e, orc_rstream *rs, int out_kind, char *err, int errlen)
+{
+    int k = a->ncomp, p = t->d;
+    int par = a->parallel;
+    int nstate = par ? k * p : p + 1;
+    int nout = t_nout(t, a, out_kind);
+    int64_t niter = (int64_t)a->nbatch * a->blen * a->nspac;
+    tdraw dr = {a, rs, e, niter, p};
+
+    double state[nstate];
+    for (int i = 0; i < nstate; i++) {
+        state[i] = a->initial[(size_t)e * nstate + i];
+        if (!isfinite(state[i])) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"initial\" must have all elements finite");
+    }
+    double L[k];
+    double xi[p], xj[p], y[p], z[p];
+    if (par) {
+        for (int i = 0; i < k; i++) {
+            for (int j = 0; j < p; j++) xi[j] = state[i + k * j];
+            L[i] = orc_lud_temper(t, i + 1, xi);
+            if (L[i] == -INFINITY) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density -Inf at initial state");
+            if (isnan(L[i]) || L[i] == INFINITY) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density function returned NA or NaN");
+        }
+    } else {
+        double ri = state[0];
+        int i = (int)ri;
+        if (i != ri) return fail(err, errlen, MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be integer in serial case");
+        if (i <= 0 || i > k) return fail(err, errlen, MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be in 1, ..., k in serial case");
+        for (int q = 0; q < k; q++) L[q] = NAN;
+        L[i - 1] = orc_lud_temper(t, i, state + 1);
+        if (L[i - 1] == -INFINITY) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density -Inf at initial state");
+    }
+
+    double ax_n[k], ax_d[k], ai_n[k][k], ai_d[k][k];
+    int nn[k], nb[k][k];
+    for (int i = 0; i < k; i++) {
+        ax_n[i] = ax_d[i] = 0;
+        nn[i] = 0;
+        for (int j = 0; j < k; j++) {
+            ai_n[i][j] = ai_d[i][j] = 0;
+            if (a->neighbors[i + k * j]) nb[i][nn[i]++] = j;
+        }
+    }
+    double buf[nout], ibuf[k], g[nout];
+    int scale_kind = a->scale_kind & 7;
+
+    int64_t it = 0;
+    for (int kb = 0; kb < a->nbatch; kb++) {
+        for (int i = 0; i < nout; i++) buf[i] = 0.0;
+        for (int i = 0; i < k; i++) ibuf[i] = 0.0;
+        for (int jb = 0; jb < a->blen; jb++) {
+            for (int is = 0; is < a->nspac; is++, it++) {
+                double uw = t_unif(&dr, it, SLOT_WHICH);
+                int within = uw < 0.5;
+                double lh;
+                int accept = 1;
+                if (within) {
+                    int i = par ? pick(t_unif(&dr, it, SLOT_CHOOSE1), k) : (int)state[0];
+                    if (par) for (int j = 0; j < p; j++) xi[j] = state[(i - 1) + k * j];
+                    else for (int j = 0; j < p; j++) xi[j] = state[1 + j];
+                    t_norm(&dr, it, z);
+                    propose_from(xi, y, z, p, scale_kind, t_scale(a, p, i));
+                    double ly = orc_lud_temper(t, i, y);
+                    if (ly == INFINITY || isnan(ly)) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density function returned NA or NaN");
+                    lh = ly - L[i - 1];
+                    if (isnan(lh) || (isinf(lh) && lh > 0)) return fail(err, errlen, MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
+                    if (lh < 0.0) accept = t_unif(&dr, it, SLOT_HAST) < exp(lh);
+                    if (accept) {
+                        if (par) for (int j = 0; j < p; j++) state[(i - 1) + k * j] = y[j];
+                        else for (int j = 0; j < p; j++) state[1 + j] = y[j];
+                        L[i - 1] = ly;
+                        ax_n[i - 1]++;
+                    }
+                    ax_d[i - 1]++;
+                } else if (par) {
+                    int i = pick(t_unif(&dr, it, SLOT_CHOOSE1), k);
+                    double u2 = t_unif(&dr, it, SLOT_CHOOSE2);
+                    int jj = nb[i - 1][pick(u2, nn[i - 1]) - 1] + 1;
+                    for (int j = 0; j < p; j++) { xi[j] = state[(i - 1) + k * j]; xj[j] = state[(jj - 1) + k * j]; }
+                    double sco = orc_lud_temper(t, jj, xi); /* (j, x_i) first (temper.c:738-739) */
+                    double spr = orc_lud_temper(t, i, xj);  /* (i, x_j) */
+                    if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY)
+                        return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density function returned NA or NaN");
+                    lh = spr + sco - L[jj - 1] - L[i - 1];   /* temper.c:742-744 */
+                    if (isnan(lh) || (isinf(lh) && lh > 0)) return fail(err, errlen, MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
+                    if (lh < 0.0) accept = t_unif(&dr, it, SLOT_HAST) < exp(lh);
+                    if (accept) {
+                        for (int j = 0; j < p; j++) { state[(jj - 1) + k * j] = xi[j]; state[(i - 1) + k * j] = xj[j]; }
+                        L[i - 1] = spr;
+                        L[jj - 1] = sco;
+                        ai_n[i - 1][jj - 1]++;
+                    }
+                    ai_d[i - 1][jj - 1]++;
+                } else {
+                    int i = (int)state[0];
+                    int jj = nb[i - 1][pick(t_unif(&dr, it, SLOT_CHOOSE1), nn[i - 1]) - 1] + 1;
+                    double ly = orc_lud_temper(t, jj, state + 1);
+                    if (ly == INFINITY || isnan(ly)) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density function returned NA or NaN");
+                    lh = ly - L[i - 1] + log((double)nn[i - 1]) - log((double)nn[jj - 1]); /* temper.c:810-812 */
+                    if (isnan(lh) || (isinf(lh) && lh > 0)) return fail(err, errlen, MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
+                    if (lh < 0.0) accept = t_unif(&dr, it, SLOT_HAST) < exp(lh);
+                    if (accept) {
+                        state[0] = jj;
+                        L[jj - 1] = ly;
+                        ai_n[i - 1][jj - 1]++;
+                    }
+                    ai_d[i - 1][jj - 1]++;
+                }
+            }
+            t_out(t, a, out_kind, state, g);
+            for (int i = 0; i < nout; i++) buf[i] += g[i];
+            if (!par) ibuf[(int)state[0] - 1]++;
+        }
+        for (int i = 0; i < nout; i++)
+            o->batch[(size_t)e * a->nbatch * nout + kb + (size_t)a->nbatch * i] = buf[i] / a->blen;
+        if (!par && o->ibatch)
+            for (int i = 0; i < k; i++)
+                o->ibatch[(size_t)e * a->nbatch * k + kb + (size_t)a->nbatch * i] = ibuf[i] / a->blen;
+    }
+    for (int i = 0; i < k; i++) o->acceptx[(size_t)e * k + i] = ax_n[i] / ax_d[i];
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++)
+            o->accepti[(size_t)e * k * k + i + k * j] = a->neighbors[i + k * j] ? ai_n[i][j] / ai_d[i][j] : NAN;
+    for (int i = 0; i < nstate; i++) o->final[(size_t)e * nstate + i] = state[i];
+    return MCMCHIP_OK;
+}
+
+int orc_temper(const mcmchip_target_desc *t, const mcmchip_temper_args *a, mcmchip_temper_out *o,
+               orc_rstream *rs, int out_kind, int nthreads, char *err, int errlen)
+{
+    int k = a->ncomp;
+    if (k <= 1) return fail(err, errlen, MCMCHIP_EINVAL, "must have at least two components");
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++)
+            if ((a->neighbors[i + k * j] != 0) != (a->neighbors[j + k * i] != 0))
+                return fail(err, errlen, MCMCHIP_EINVAL, "argument \"neighbors\" must be symmetric matrix");
+    if (a->nbatch <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"nbatch\" must be positive");
+    if (a->blen <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"blen\" must be positive");
+    if (a->nspac <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"nspac\" must be positive");
+    if (scale_len(a->scale_kind, t->d) < 0) return fail(err, errlen, MCMCHIP_EINVAL, "scale not matrix, scalar, or vector of length k");
+    if (t_nout(t, a, out_kind) < 0) return fail(err, errlen, MCMCHIP_EINVAL, "bad out_kind");
+    o->iter_offset_out = a->iter_offset + (uint64_t)a->nbatch * a->blen * a->nspac;
+    if (a->rng_mode == ORC_RNG_RSTREAM || nthreads <= 1) {
+        for (int64_t e = 0; e < a->nens; e++) {
+            int rc = temper_ens(t, a, o, e, rs, out_kind, err, errlen);
+            if (rc) return rc;
+        }
+        return MCMCHIP_OK;
+    }
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t e = 0; e < a->nens; e++) {
+        char m[256];
+        int r = temper_ens(t, a, o, e, NULL, out_kind, m, sizeof m);
+        if (r) {
+#pragma omp critical
+            { if (!bad) { bad = r; if (err) snprintf(err, (size_t)errlen, "%s", m); } }
+        }
+    }
+    return bad;
+}
+
+/* ------------------------------------------------------------------ */
+/* initseq (initseq.c:7-128), one column                                 */
+/* ------------------------------------------------------------------ */
+int64_t orc_initseq(const double *x, int64_t len, int64_t cap, double *gamma0, double *Gpos,
+                    double *Gdec, double *Gcon, double *var_pos, double *var_dec, double *var_con)
+{
+    int64_t half = len / 2;
+    double *buff = (double *)malloc(sizeof(double) * (size_t)(half > 0 ? half : 1));
+    int64_t i;
+    double g0 = 0.0;
+    for (i = 0; i < half; ++i) {
+        int64_t lag1 = 2 * i, lag2 = lag1 + 1;
+        double gam1 = 0.0, gam2 = 0.0;
+        for (int64_t j = 0; j + lag1 < len; ++j) gam1 += x[j] * x[j + lag1];
+        gam1 /= len;
+        if (i == 0) g0 = gam1;
+        for (int64_t j = 0; j + lag2 < len; ++j) gam2 += x[j] * x[j + lag2];
+        gam2 /= len;
+        buff[i] = gam1 + gam2;
+        if (buff[i] < 0.0) { buff[i] = 0.0; ++i; break; }   /* initseq.c:42-46 */
+    }
+    int64_t m = i;
+    *gamma0 = g0;
+    if (m > cap) { free(buff); return m; }
+    for (int64_t j = 0; j < m; ++j) Gpos[j] = buff[j];
+    for (int64_t j = 1; j < m; ++j)
+        if (buff[j] > buff[j - 1]) buff[j] = buff[j - 1];    /* running min, initseq.c:55-57 */
+    for (int64_t j = 0; j < m; ++j) Gdec[j] = buff[j];
+    for (int64_t j = m - 1; j > 0; --j) buff[j] -= buff[j - 1];
+    /* PAVA on the first differences (initseq.c:66-80) */
+    double *puff = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    int64_t *nuff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m > 0 ? m : 1));
+    int64_t nstep = 0;
+    for (int64_t j = 1; j < m; ++j) {
+        puff[nstep] = buff[j];
+        nuff[nstep] = 1;
+        ++nstep;
+        while (nstep > 1 && puff[nstep - 1] / nuff[nstep - 1] < puff[nstep - 2] / nuff[nstep - 2]) {
+            puff[nstep - 2] += puff[nstep - 1];
+            nuff[nstep - 2] += nuff[nstep - 1];
+            --nstep;
+        }
+    }
+    for (int64_t js = 0, j = 1; js < nstep; ++js) {
+        double muff = puff[js] / nuff[js];
+        for (int64_t q = 0; q < nuff[js]; ++j, ++q) buff[j] = buff[j - 1] + muff;
+    }
+    for (int64_t j = 0; j < m; ++j) Gcon[j] = buff[j];
+    double vp = 0.0, vd = 0.0, vc = 0.0;
+    for (int64_t j = 0; j < m; ++j) { vp += Gpos[j]; vd += Gdec[j]; vc += Gcon[j]; }
+    *var_pos = vp * 2.0 - g0;
+    *var_dec = vd * 2.0 - g0;
+    *var_con = vc * 2.0 - g0;
+    free(buff); free(puff); free(nuff);
+    return m;
+}
+
+/* ------------------------------------------------------------------ */
+/* olbm (olbm.c:22-78)                                                   */
+/* ------------------------------------------------------------------ */
+int orc_olbm(const double *x, int64_t n, int p, int64_t len, double *mean, double *var, int nocalc)
+{
+    if (len > n) return MCMCHIP_EINVAL; /* "len > n\n" */
+    double nbatch = (double)(n - len + 1);
+    double *work = (double *)malloc(sizeof(double) * (size_t)p);
+    if (!nocalc)
+        for (int i = 0; i < p; i++) {
+            double s = 0.0;
+            for (int64_t t = 0; t < n; t++) s += x[t + n * i];
+            mean[i] = s / n;
+        }
+    for (int i = 0; i < p; i++) mean[i] *= len;
+    for (int i = 0; i < p; i++) {
+        work[i] = 0.0;
+        for (int64_t t = 0; t < len; t++) work[i] += x[t + n * i];
+        for (int j = i; j >= 0; j--) var[i + p * j] = (work[i] - mean[i]) * (work[j] - mean[j]);
+    }
+    for (int64_t lo = 0, hi = len; hi < n; lo++, hi++)
+        for (int i = 0; i < p; i++) {
+            work[i] -= x[lo + n * i];
+            work[i] += x[hi + n * i];
+            for (int j = i; j >= 0; j--) var[i + p * j] += (work[i] - mean[i]) * (work[j] - mean[j]);
+        }
+    for (int i = 0; i < p; i++) mean[i] /= len;
+    for (int i = 0; i < p; i++)
+        for (int j = 0; j <= i; j++) {
+            var[i + p * j] /= nbatch * n * len;
+            if (j < i) var[j + p * i] = var[i + p * j];
+        }
+    free(work);
+    return MCMCHIP_OK;
+}
