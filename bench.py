@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- chain-iterations/sec of batched metrop on the synthetic logistic posterior
+(BASELINE.json config 3: n = 1e6 observations, d = 64, 65 536 chains per GPU, fp64, device Philox).
+
+One "step" = one lockstep Metropolis iteration of every chain on this rank: Philox normals ->
+proposal -> log density (fp64 MFMA X.Theta + softplus) -> accept/reject -> batch means.
+Inputs (X tiles, y, initial states) are resident in HBM before the timed region; outputs stay
+in HBM.  N > 1: one process per GPU (torchrun), chains sharded (weak scaling: 65 536 per GPU),
+no per-iteration communication, one small RCCL all-gather of per-rank summaries at the end.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X vendor peak, fp64 matrix (= vector) -- see DESIGN.md "Roofline"
+
+
+def synthetic(n, d, seed=42):
+    """SURVEY.md 8(d) C3 inputs"""
+    rng = np.random.default_rng(seed)
+    X = np.empty((n, d))
+    X[:, 0] = 1.0
+    X[:, 1:] = rng.standard_normal((n, d - 1)) / np.sqrt(d)
+    beta = 0.5 * rng.standard_normal(d)
+    y = (rng.random(n) < 1.0 / (1.0 + np.exp(-(X @ beta)))).astype(np.float64)
+    return X, y, beta
+
+
+def cpu_baseline(X, y, beta, scale, threads, budget_s=12.0):
+    """the oracle (CPU restatement of the reference loop + the same descriptor), one chain per
+    thread, on a bounded sample of the same workload"""
+    import oracle
+    from mcmc_amd import abi
+    oracle.build()
+    tg = oracle.Target(abi.T_LOGISTIC, X.shape[1], x=X, y=y, prior_c=0.125)
+    d = X.shape[1]
+    init = beta + 1e-3 * np.random.default_rng(1).standard_normal((threads, d))
+    t0 = time.perf_counter()
+    oracle.metrop(tg, init, 1, scale=scale, seed=1, nthreads=threads)      # 2 density evaluations per chain
+    per_eval = (time.perf_counter() - t0) / 2.0
+    iters = int(max(2, min(40, budget_s / max(per_eval, 1e-6) - 1)))
+    t0 = time.perf_counter()
+    oracle.metrop(tg, init, iters, scale=scale, seed=1, nthreads=threads)
+    el = time.perf_counter() - t0
+    return {"value": threads * iters / el, "unit": "chain-iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d chains (one per thread) x %d iterations of the same n=%d, d=%d posterior, %.1f s"
+                      % (threads, iters, X.shape[0], d, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--scale", type=float, default=1.0e-3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mcmc_amd import abi, api
+    api.init(local_rank)
+    L = api.load_library()
+
+    X, y, beta = synthetic(a.n, a.d)
+    tg = api.logistic_target(X, y)                      # X staged and pre-tiled in HBM once
+    Cn, d = a.chains, a.d
+    chain0 = rank * Cn                                  # global chain ids: results independent of N
+    init_h = beta + 1e-3 * np.random.default_rng(1000 + rank).standard_normal((Cn, d))
+    init = torch.from_numpy(init_h).to(dev)
+
+    def run(nbatch, initial, iter_offset):
+        out_accept = torch.empty(Cn, dtype=torch.float64, device=dev)
+        out_batch = torch.empty((Cn, nbatch, d), dtype=torch.float64, device=dev)
+        out_final = torch.empty((Cn, d), dtype=torch.float64, device=dev)
+        out_ab = torch.empty((Cn, nbatch), dtype=torch.float64, device=dev)
+        scale = np.array([a.scale])
+        args = abi.MetropArgs(Cn, nbatch, 1, 1, initial.data_ptr(), abi.SCALE_CONSTANT, scale.ctypes.data,
+                              abi.OUT_IDENTITY, None, abi.RNG_PHILOX, None, None, 20240607, chain0, iter_offset,
+                              0, 1, abi.PATH_MFMA)
+        out = abi.MetropOut(out_accept.data_ptr(), out_batch.data_ptr(), out_final.data_ptr(), out_ab.data_ptr(),
+                            None, None, None, None, None, None, 0, 0, 0)
+        torch.cuda.synchronize()
+        rc = L.mcmchip_metrop(tg.handle, C.addressof(args), C.addressof(out))
+        if rc:
+            raise RuntimeError(L.mcmchip_last_error().decode())
+        return out_accept, out_batch, out_final, int(out.iter_offset_out)
+
+    # warmup (untimed)
+    state, off = init, 0
+    if a.warmup > 0:
+        _, _, state, off = run(a.warmup, init, 0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    acc, batch, state, off = run(a.steps, state, off)
+    # the one collective of the path: per-rank summaries (acceptance rate, mean of the batch means)
+    summ = torch.cat([acc.mean().reshape(1), batch.mean(dim=(0, 1))])
+    if world > 1:
+        allsum = [torch.empty_like(summ) for _ in range(world)]
+        dist.all_gather(allsum, summ)
+        summ = torch.stack(allsum).mean(dim=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kname, kms, klaunch = api.last_kernel_time()
+    if rank == 0:
+        flops_per_launch = 2.0 * a.n * a.d * Cn
+        achieved = flops_per_launch / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        res = {
+            "metric": "chain-iterations/sec per node, batched metrop on logistic posterior",
+            "value": world * Cn * a.steps / elapsed,
+            "unit": "chain-iterations/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3: synthetic logistic posterior n=%d d=%d, %d chains per GPU, "
+                                   "scalar scale %.2g, identity outfun, device Philox, blen=nspac=1"
+                                   % (a.n, a.d, Cn, a.scale),
+                       "chains_per_gpu": Cn, "n": a.n, "d": a.d, "parallelism": "chains sharded x%d" % world,
+                       "accept_rate": float(summ[0].item()),
+                       "note": "timed call = %d iterations + the call's initial-state density evaluation" % a.steps},
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "launch_ms": kms, "launches_timed": klaunch,
+                         "flops_per_launch": flops_per_launch},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                threads = min(16, len(os.sched_getaffinity(0)))
+                res["cpu_baseline"] = cpu_baseline(X, y, beta, a.scale, threads)
+            except Exception as e:          # the baseline is a reported extra, never the product path
+                res["cpu_baseline"] = {"value": None, "error": str(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's R front ends for the hot path.
+
+    metrop()   R/metrop.R:2-67      temper()  R/temper.R:2-75
+    initseq()  R/initseq.R:1-5      olbm()    R/olbm.R:2-24
+
+Same argument names, meaning and error behaviour; `obj` is a log-density *descriptor*
+(`Target`) instead of an R closure, or the result of a previous run (restart semantics of
+R/metrop.R:6-27).  All compute goes through the C-ABI of include/mcmchip.h into
+libmcmchip.so (hand-written HIP).  There is NO CPU fallback: if the library is missing or no
+GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_INIT_DEVICE = None
+
+
+class McmcHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libmcmchip.so")
+
+
+def load_library():
+    """dlopen libmcmchip.so and declare the prototypes of include/mcmchip.h (no GPU needed)"""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise McmcHipError(abi.EHIP, "libmcmchip.so is not built: run `make -C mcmc_amd/csrc` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(path)
+    L.mcmchip_init.argtypes = [C.c_int]
+    L.mcmchip_init.restype = C.c_int
+    L.mcmchip_last_error.restype = C.c_char_p
+    L.mcmchip_version.restype = C.c_char_p
+    L.mcmchip_target_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.mcmchip_target_create.restype = C.c_int
+    L.mcmchip_target_destroy.argtypes = [C.c_void_p]
+    L.mcmchip_target_destroy.restype = None
+    L.mcmchip_logdens.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+    L.mcmchip_logdens.restype = C.c_int
+    L.mcmchip_metrop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mcmchip_metrop.restype = C.c_int
+    L.mcmchip_temper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mcmchip_temper.restype = C.c_int
+    L.mcmchip_initseq.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64] + [C.c_void_p] * 8
+    L.mcmchip_initseq.restype = C.c_int
+    L.mcmchip_olbm.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                               C.c_int32, C.c_int]
+    L.mcmchip_olbm.restype = C.c_int
+    L.mcmchip_last_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    L.mcmchip_last_kernel_time.restype = C.c_int
+    L.mcmchip_sync.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != abi.OK:
+        raise McmcHipError(rc, load_library().mcmchip_last_error().decode())
+
+
+def init(device=None):
+    """select the HIP device (default: LOCAL_RANK, else 0)"""
+    global _INIT_DEVICE
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if _INIT_DEVICE is None else _INIT_DEVICE
+    if _INIT_DEVICE != device:
+        _check(load_library().mcmchip_init(int(device)))
+        _INIT_DEVICE = device
+    return device
+
+
+def last_kernel_time():
+    """(name, average ms per launch, launches) of the dominant kernel of the last call"""
+    ms, n = C.c_double(), C.c_int64()
+    name = C.create_string_buffer(64)
+    _check(load_library().mcmchip_last_kernel_time(C.byref(ms), C.byref(n), name, 64))
+    return name.value.decode(), ms.value, n.value
+
+
+class Target(abi.HostTarget):
+    """Log unnormalised density descriptor, resident in HBM (replaces `obj`/`lud`)."""
+
+    def __init__(self, kind, d, x=None, y=None, prior_c=0.0, par=None, device=None):
+        super().__init__(kind, d, x=x, y=y, prior_c=prior_c, par=par)
+        init(device)
+        h = C.c_void_p()
+        _check(load_library().mcmchip_target_create(C.addressof(self.desc), 0, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load_library().mcmchip_target_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def logistic_target(x, y, prior_sd=2.0, device=None):
+    """the vignette's posterior (demo.Rnw:59-65): iid N(0, prior_sd^2) prior on the coefficients"""
+    x = np.asarray(x, dtype=np.float64)
+    return Target(abi.T_LOGISTIC, x.shape[1], x=x, y=y, prior_c=1.0 / (2.0 * prior_sd ** 2), device=device)
+
+
+def logdens(target, states, path=abi.PATH_AUTO):
+    s = np.ascontiguousarray(states, dtype=np.float64)
+    if s.ndim == 1:
+        s = s[None]
+    out = np.empty(s.shape[0])
+    _check(load_library().mcmchip_logdens(target.handle, s.ctypes.data, s.shape[0], int(path), 0,
+                                          out.ctypes.data))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=None, outfun=None, debug=None,
+           seed=None, z=None, u=None, path=abi.PATH_AUTO, chain_offset=0, _iter_offset=0):
+    """metrop(obj, initial, nbatch, blen = 1, nspac = 1, scale = 1, outfun, debug = FALSE)
+
+    obj     a Target, or the dict returned by a previous call (then missing arguments default
+            to the previous ones, the run starts at obj["final"] and continues the same random
+            stream: R/metrop.R:6-27, tests/saveseed.R)
+    initial d-vector (one chain, result shapes as in R) or nchain x d matrix (batched extension:
+            results gain a leading chain axis)
+    seed    key of the device Philox stream (the role of .Random.seed); z, u: injected streams
+            (parity mode)
+    Returns a dict with the reference's names: accept, batch, initial, final, accept.batch
+    [, current, proposal, log.green, u, z, debug.accept], initial.seed, final.seed, time, lud,
+    nbatch, blen, nspac, scale, outfun, debug.
+    """
+    if isinstance(obj, dict):
+        prev = obj
+        target = prev["lud"]
+        initial = prev["final"] if initial is None else initial
+        nbatch = prev["nbatch"] if nbatch is None else nbatch
+        # missing(blen) etc. take the value stored in the object (R/metrop.R:9-15)
+        blen = prev["blen"] if blen is None else blen
+        nspac = prev["nspac"] if nspac is None else nspac
+        scale = prev["scale"] if scale is None else scale
+        debug = prev["debug"] if debug is None else debug
+        outfun = prev["outfun"] if outfun is None else outfun
+        seed = prev["final.seed"][0] if seed is None else seed
+        _iter_offset = prev["final.seed"][1]
+        chain_offset = prev["final.seed"][2]
+    else:
+        target = obj
+    blen = 1 if blen is None else blen          # defaults of R/metrop.R:2-3
+    nspac = 1 if nspac is None else nspac
+    scale = 1 if scale is None else scale
+    debug = False if debug is None else debug
+    if not isinstance(target, Target):
+        raise TypeError('argument "obj" must be a Target (log-density descriptor) or a previous result')
+    if initial is None or nbatch is None:
+        raise ValueError('argument "initial"/"nbatch" missing')
+    single = np.ndim(initial) == 1
+    if z is not None or u is not None:
+        mode = abi.RNG_INJECTED
+    else:
+        mode = abi.RNG_PHILOX
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+    call = abi.MetropCall(target.d, initial, nbatch, blen, nspac, scale, outfun, rng_mode=mode, z=z, u=u,
+                          seed=seed or 0, chain_offset=chain_offset, iter_offset=_iter_offset,
+                          debug=debug, path=path)
+    t0 = time.perf_counter()
+    _check(load_library().mcmchip_metrop(target.handle, C.addressof(call.args), C.addressof(call.out)))
+    elapsed = time.perf_counter() - t0
+    r = call.result()
+
+    def sq(a):
+        return a[0] if single else a
+
+    out = {"accept": sq(r["accept"]), "batch": sq(r["batch"]), "initial": sq(r["initial"]),
+           "final": sq(r["final"]), "accept.batch": sq(r["accept_batch"])}
+    if debug:
+        out.update({"current": sq(r["current"]), "proposal": sq(r["proposal"]),
+                    "log.green": sq(r["log_green"]), "u": sq(r["u"]), "z": sq(r["z"]),
+                    "debug.accept": sq(r["debug_accept"]).astype(bool)})
+    out.update({"initial.seed": (seed, _iter_offset, chain_offset),
+                "final.seed": (seed, r["iter_offset"], chain_offset),
+                "time": elapsed, "lud": target, "nbatch": int(nbatch), "blen": int(blen),
+                "nspac": int(nspac), "scale": scale})
+    if outfun is not None:
+        out["outfun"] = outfun
+    else:
+        out["outfun"] = None
+    out["debug"] = bool(debug)
+    out["path"] = {abi.PATH_STREAM: "stream", abi.PATH_MFMA: "mfma"}.get(r["path_used"], "?")
+    return out
+
+
+def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None, scale=None, outfun=None,
+           debug=None, parallel=None, seed=None, unif=None, norm=None, ens_offset=0, _iter_offset=0):
+    """temper(obj, initial, neighbors, nbatch, blen = 1, nspac = 1, scale = 1, outfun,
+              debug = FALSE, parallel = FALSE)   -- R/temper.R:2-75
+
+    initial  parallel: k x p matrix (or nens x k x p); serial: c(i, x) (or nens x (1+p))
+    Returns the reference's names: lud, neighbors, nbatch, blen, nspac, scale, outfun, debug,
+    parallel, initial.seed, final.seed, time, batch, acceptx, accepti, initial, final [, ibatch].
+    outfun functions and debug traces are not available on the device path.
+    """
+    if isinstance(obj, dict):
+        prev = obj
+        target = prev["lud"]
+        initial = prev["final"] if initial is None else initial
+        neighbors = prev["neighbors"] if neighbors is None else neighbors
+        nbatch = prev["nbatch"] if nbatch is None else nbatch
+        blen = prev["blen"] if blen is None else blen      # R/temper.R:6-35
+        nspac = prev["nspac"] if nspac is None else nspac
+        scale = prev["scale"] if scale is None else scale
+        parallel = prev["parallel"] if parallel is None else parallel
+        seed = prev["final.seed"][0] if seed is None else seed
+        _iter_offset = prev["final.seed"][1]
+        ens_offset = prev["final.seed"][2]
+    else:
+        target = obj
+    blen = 1 if blen is None else blen
+    nspac = 1 if nspac is None else nspac
+    scale = 1 if scale is None else scale
+    parallel = False if parallel is None else parallel
+    if not isinstance(target, Target) or not target.is_temper_kind:
+        raise TypeError('argument "obj" must be a tempering Target or a previous result')
+    if outfun is not None:
+        raise NotImplementedError("temper: outfun functions cannot run on the device path")
+    if debug:
+        raise NotImplementedError("temper: debug traces are not produced by the device path")
+    init_arr = np.asarray(initial, dtype=np.float64)
+    single = init_arr.ndim == (2 if parallel else 1)
+    if unif is not None or norm is not None:
+        mode = abi.RNG_INJECTED
+    else:
+        mode = abi.RNG_PHILOX
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+    call = abi.TemperCall(target.d, init_arr, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=mode,
+                          unif=unif, norm=norm, seed=seed or 0, ens_offset=ens_offset,
+                          iter_offset=_iter_offset)
+    t0 = time.perf_counter()
+    _check(load_library().mcmchip_temper(target.handle, C.addressof(call.args), C.addressof(call.out)))
+    elapsed = time.perf_counter() - t0
+    r = call.result()
+
+    def sq(a):
+        return a[0] if single else a
+
+    out = {"lud": target, "neighbors": np.asarray(neighbors, dtype=bool), "nbatch": int(nbatch),
+           "blen": int(blen), "nspac": int(nspac), "scale": scale, "outfun": None, "debug": False,
+           "parallel": bool(parallel), "initial.seed": (seed, _iter_offset, ens_offset),
+           "final.seed": (seed, r["iter_offset"], ens_offset), "time": elapsed,
+           "batch": sq(r["batch"]), "acceptx": sq(r["acceptx"]), "accepti": sq(r["accepti"]),
+           "initial": init_arr, "final": sq(r["final"])}
+    if not parallel:
+        out["ibatch"] = sq(r["ibatch"])
+    return out
+
+
+def initseq(x):
+    """initseq(x): R/initseq.R:1-5 -- x numeric, all finite; the series is centred here and the
+    centred series goes to the native routine.  A 2-d x (len x ncol) is a batch of series and
+    returns a list of results."""
+    x = np.asarray(x)
+    if not np.issubdtype(x.dtype, np.number):
+        raise TypeError("is.numeric(x) is not TRUE")
+    x = x.astype(np.float64)
+    if not np.all(np.isfinite(x)):
+        raise ValueError("all(is.finite(x)) is not TRUE")
+    single = x.ndim == 1
+    xm = x[:, None] if single else x
+    length, ncol = xm.shape
+    xc = np.ascontiguousarray((xm - xm.mean(axis=0)).T)      # column-major len x ncol
+    init()
+    L = load_library()
+    cap = max(min(length // 2, 4096), 1)
+    while True:
+        n_out = np.zeros(ncol, dtype=np.int64)
+        g0, vp, vd, vc = (np.empty(ncol) for _ in range(4))
+        Gp, Gd, Gc = (np.empty((ncol, cap)) for _ in range(3))
+        rc = L.mcmchip_initseq(xc.ctypes.data, length, ncol, 0, cap, n_out.ctypes.data, g0.ctypes.data,
+                               Gp.ctypes.data, Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data,
+                               vd.ctypes.data, vc.ctypes.data)
+        if rc == abi.ECAP:
+            cap = int(n_out.max())
+            continue
+        _check(rc)
+        break
+    res = []
+    for c in range(ncol):
+        m = int(n_out[c])
+        res.append({"gamma0": g0[c], "Gamma.pos": Gp[c, :m].copy(), "Gamma.dec": Gd[c, :m].copy(),
+                    "Gamma.con": Gc[c, :m].copy(), "var.pos": vp[c], "var.dec": vd[c], "var.con": vc[c]})
+    return res[0] if single else res
+
+
+def olbm(x, batch_length, demean=True):
+    """olbm(x, batch.length, demean = TRUE): R/olbm.R:2-24.  x is n x p (a vector is n x 1).
+    Like the reference, demean = FALSE zeroes `mean` but leaves no.calc.mean FALSE, so the
+    native routine recomputes the means (R/olbm.R:8-14 with olbm.c:37): both settings demean."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+    n, p = x.shape
+    batch_length = int(batch_length)
+    if batch_length > n:
+        raise ValueError("batch.length must be <= nrow(x)")
+    xc = np.ascontiguousarray(x.T)                           # column-major n x p
+    if demean:
+        mean = x.mean(axis=0)
+        no_calc_mean = True
+    else:
+        mean = np.zeros(p)
+        no_calc_mean = False
+    mean = np.ascontiguousarray(mean, dtype=np.float64)
+    var = np.empty((p, p))
+    init()
+    _check(load_library().mcmchip_olbm(xc.ctypes.data, n, p, batch_length, mean.ctypes.data,
+                                       var.ctypes.data, int(no_calc_mean), 0))
+    return var

@@ -1,0 +1,479 @@
+// capi.hip -- the extern "C" entry points of include/mcmchip.h: argument validation with the
+// reference's error texts, staging of host buffers through HBM, path selection, error flags.
+#include "kernels.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+void clear_error() { g_err[0] = 0; }
+
+LibCtx &lib_ctx()
+{
+    static LibCtx c;
+    return c;
+}
+
+DeviceCtx *cur_dev()
+{
+    LibCtx &L = lib_ctx();
+    if (L.device < 0 || !L.dev[L.device].inited) {
+        set_error(MCMCHIP_EHIP, "mcmchip_init() has not been called (no HIP device selected)");
+        return nullptr;
+    }
+    if (hipSetDevice(L.device) != hipSuccess) {
+        set_error(MCMCHIP_EHIP, "hipSetDevice(%d) failed", L.device);
+        return nullptr;
+    }
+    return &L.dev[L.device];
+}
+
+void timing_reset(const char *name)
+{
+    LibCtx &L = lib_ctx();
+    L.ev_used = 0;
+    snprintf(L.ev_name, sizeof L.ev_name, "%s", name);
+}
+static const int EV_MAX = 256;
+void timing_begin(hipStream_t s)
+{
+    LibCtx &L = lib_ctx();
+    if (L.ev_used >= EV_MAX) return;
+    if ((int)L.ev_start.size() <= L.ev_used) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        L.ev_start.push_back(a);
+        L.ev_stop.push_back(b);
+    }
+    (void)hipEventRecord(L.ev_start[L.ev_used], s);
+}
+void timing_end(hipStream_t s)
+{
+    LibCtx &L = lib_ctx();
+    if (L.ev_used >= EV_MAX || (int)L.ev_stop.size() <= L.ev_used) return;
+    (void)hipEventRecord(L.ev_stop[L.ev_used], s);
+    L.ev_used++;
+}
+
+extern "C" {
+
+const char *mcmchip_last_error(void) { return g_err; }
+const char *mcmchip_version(void) { return "mcmchip 0.1 (gfx950)"; }
+
+int mcmchip_init(int device)
+{
+    clear_error();
+    if (device < 0 || device >= MCMCHIP_MAX_DEVICES) return set_error(MCMCHIP_EINVAL, "bad device index %d", device);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device >= ndev) return set_error(MCMCHIP_EHIP, "device %d requested but only %d visible", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    LibCtx &L = lib_ctx();
+    DeviceCtx &D = L.dev[device];
+    if (!D.inited) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        D.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+        SoftplusTables host;
+        softplus_tables_init(&host);
+        HIP_TRY(hipMalloc((void **)&D.d_tables, sizeof host));
+        HIP_TRY(hipMemcpy(D.d_tables, &host, sizeof host, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&D.d_flag, 256));
+        HIP_TRY(hipMemset(D.d_flag, 0, 256));
+        D.inited = true;
+    }
+    L.device = device;
+    return MCMCHIP_OK;
+}
+
+int mcmchip_sync(void)
+{
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    HIP_TRY(hipStreamSynchronize(dc->stream));
+    return MCMCHIP_OK;
+}
+
+int mcmchip_last_kernel_time(double *avg_ms, int64_t *launches, char *name, int name_cap)
+{
+    LibCtx &L = lib_ctx();
+    double tot = 0.0;
+    int n = 0;
+    for (int i = 0; i < L.ev_used; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(L.ev_stop[i]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, L.ev_start[i], L.ev_stop[i]) != hipSuccess) continue;
+        tot += ms;
+        n++;
+    }
+    if (avg_ms) *avg_ms = n ? tot / n : 0.0;
+    if (launches) *launches = n;
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", L.ev_name);
+    return MCMCHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static bool is_logistic(int kind) { return kind == MCMCHIP_T_LOGISTIC || kind == MCMCHIP_T_LOGISTIC_NAIVE; }
+static bool is_temper_kind(int kind) { return kind == MCMCHIP_T_WITCH || kind == MCMCHIP_T_TEMPERED_NORMMIX; }
+
+int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs, mcmchip_target **out)
+{
+    clear_error();
+    if (!desc || !out) return set_error(MCMCHIP_EINVAL, "null argument");
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_TEMPERED_NORMMIX)
+        return set_error(MCMCHIP_EINVAL, "unknown log density descriptor kind %d", desc->kind);
+    if (desc->d <= 0) return set_error(MCMCHIP_EINVAL, "descriptor dimension must be positive");
+    mcmchip_target *t = new mcmchip_target();
+    t->kind = desc->kind; t->d = desc->d; t->prior_c = desc->prior_c; t->device = lib_ctx().device;
+    hipMemcpyKind kind = desc_device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    int rc = MCMCHIP_OK;
+    do {
+        if (is_logistic(desc->kind)) {
+            if (desc->n <= 0 || !desc->x || !desc->y) { rc = set_error(MCMCHIP_EINVAL, "logistic descriptor needs x (n x d) and y (n)"); break; }
+            t->n = desc->n;
+            size_t xb = (size_t)desc->n * desc->d * 8, yb = (size_t)desc->n * 8;
+            if (hipMalloc((void **)&t->x, xb) != hipSuccess || hipMalloc((void **)&t->y, yb) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc of the design matrix failed"); break; }
+            if (hipMemcpyAsync(t->x, desc->x, xb, kind, dc->stream) != hipSuccess ||
+                hipMemcpyAsync(t->y, desc->y, yb, kind, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of the design matrix failed"); break; }
+            if (desc->kind == MCMCHIP_T_LOGISTIC && desc->d <= MCMCHIP_MFMA_MAXD) {
+                rc = build_mfma_tiles(t, dc->stream);
+                if (rc) break;
+            }
+        }
+        if (desc->npar > 0 && desc->par) {
+            t->npar = desc->npar;
+            if (hipMalloc((void **)&t->par, (size_t)desc->npar * 8) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc failed"); break; }
+            if (hipMemcpyAsync(t->par, desc->par, (size_t)desc->npar * 8, kind, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of descriptor parameters failed"); break; }
+            if (!desc_device_ptrs) t->host_par.assign(desc->par, desc->par + desc->npar);
+        } else if (!is_logistic(desc->kind) && desc->kind != MCMCHIP_T_BALL) {
+            rc = set_error(MCMCHIP_EINVAL, "descriptor kind %d needs a parameter block", desc->kind);
+            break;
+        }
+        if (hipStreamSynchronize(dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "stream synchronize failed"); break; }
+    } while (0);
+    if (rc) { mcmchip_target_destroy(t); return rc; }
+    *out = t;
+    return MCMCHIP_OK;
+}
+
+void mcmchip_target_destroy(mcmchip_target *t)
+{
+    if (!t) return;
+    if (t->x) (void)hipFree(t->x);
+    if (t->y) (void)hipFree(t->y);
+    if (t->par) (void)hipFree(t->par);
+    if (t->xt) (void)hipFree(t->xt);
+    delete t;
+}
+
+static int check_flag(DeviceCtx *dc, bool temper)
+{
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, dc->d_flag, sizeof flag, hipMemcpyDeviceToHost, dc->stream));
+    HIP_TRY(hipStreamSynchronize(dc->stream));
+    if (!flag) return MCMCHIP_OK;
+    if (flag & FLAG_NEGINF_INIT) return set_error(MCMCHIP_EDOMAIN, "log unnormalized density -Inf at initial state");
+    if (flag & FLAG_POSINF) return set_error(MCMCHIP_EDOMAIN, temper ? "log unnormalized density function returned +Inf" : "logh: func returned +Inf");
+    if (flag & FLAG_NAN) return set_error(MCMCHIP_EDOMAIN, temper ? "log unnormalized density function returned NA or NaN" : "logh: func returned NA or NaN");
+    return set_error(MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
+}
+
+int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchain, int path,
+                    int device_ptrs, double *out)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!t || !states || !out || nchain <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_logdens");
+    int w = is_temper_kind(t->kind) ? t->d + 1 : t->d;
+    InBuf in;
+    OutBuf ob;
+    HIP_TRY(in.set(states, (size_t)nchain * w * 8, device_ptrs, dc->stream));
+    HIP_TRY(ob.set(out, (size_t)nchain * 8, device_ptrs));
+    bool mfma = (path == MCMCHIP_PATH_MFMA) || (path == MCMCHIP_PATH_AUTO && t->xt && t->n >= 4096 && nchain >= 64);
+    int rc;
+    if (mfma) rc = launch_logdens_mfma(t, in.as<double>(), nchain, ob.as<double>(), dc);
+    else rc = launch_logdens_stream(t, in.as<double>(), nchain, ob.as<double>(), dc->stream);
+    if (rc) return rc;
+    HIP_TRY(ob.finish(dc->stream));
+    HIP_TRY(hipStreamSynchronize(dc->stream));
+    return MCMCHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchip_metrop_out *o)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!t || !a || !o) return set_error(MCMCHIP_EINVAL, "null argument");
+    if (is_temper_kind(t->kind)) return set_error(MCMCHIP_EINVAL, "descriptor kind %d is a tempering target", t->kind);
+    // argument checks in the reference's order and words (metrop.c:40-74)
+    if (!a->initial) return set_error(MCMCHIP_EINVAL, "argument \"initial\" must be numeric");
+    if (!a->scale) return set_error(MCMCHIP_EINVAL, "argument \"scale\" must be numeric");
+    if (a->nbatch <= 0) return set_error(MCMCHIP_EINVAL, "argument \"nbatch\" must be positive");
+    if (a->blen <= 0) return set_error(MCMCHIP_EINVAL, "argument \"blen\" must be positive");
+    if (a->nspac <= 0) return set_error(MCMCHIP_EINVAL, "argument \"nspac\" must be positive");
+    if (a->nchain <= 0) return set_error(MCMCHIP_EINVAL, "nchain must be positive");
+    const int d = t->d;
+    const long nchain = a->nchain;
+    const long niter = (long)a->nbatch * a->blen * a->nspac;
+    size_t slen;
+    switch (a->scale_kind) {
+    case MCMCHIP_SCALE_CONSTANT: slen = 1; break;
+    case MCMCHIP_SCALE_DIAGONAL: slen = d; break;
+    case MCMCHIP_SCALE_FULL: slen = (size_t)d * d; break;
+    default: return set_error(MCMCHIP_EINVAL, "length of \"scale\" vector not d or 1");
+    }
+    if (!a->device_ptrs) {
+        for (size_t i = 0; i < (size_t)nchain * d; i++)
+            if (!isfinite(a->initial[i])) return set_error(MCMCHIP_EINVAL, "all elements of \"state\" must be finite");
+    }
+    // output functional -> index map (metrop.c:416-503 already resolved to a mask by the caller)
+    std::vector<int> map;
+    int sq_from;
+    if (a->out_kind == MCMCHIP_OUT_IDENTITY) {
+        for (int j = 0; j < d; j++) map.push_back(j);
+        sq_from = d;
+    } else if (a->out_kind == MCMCHIP_OUT_MOMENTS2) {
+        for (int j = 0; j < 2 * d; j++) map.push_back(j % d);
+        sq_from = d;
+    } else if (a->out_kind == MCMCHIP_OUT_INDEX) {
+        if (!a->out_index) return set_error(MCMCHIP_EINVAL, "outfun must be NULL, a function, a numeric vector, or a logical vector");
+        for (int j = 0; j < d; j++) if (a->out_index[j]) map.push_back(j);
+        sq_from = (int)map.size();
+    } else {
+        return set_error(MCMCHIP_EINVAL, "outfun must be NULL, a function, a numeric vector, or a logical vector");
+    }
+    const int nout = (int)map.size();
+    if (nout == 0) { map.push_back(0); }
+    if (a->rng_mode == MCMCHIP_RNG_INJECTED) {
+        if (!a->z || !a->u) return set_error(MCMCHIP_EINVAL, "injected random streams z and u are required in parity mode");
+    } else if (a->rng_mode != MCMCHIP_RNG_PHILOX) {
+        return set_error(MCMCHIP_EINVAL, "unknown rng_mode %d", a->rng_mode);
+    }
+    if (a->debug && (!o->current || !o->proposal || !o->z || !o->log_green || !o->u || !o->debug_accept))
+        return set_error(MCMCHIP_EINVAL, "debug requested but trace outputs are NULL");
+    if (!o->accept || !o->batch || !o->final || !o->accept_batch) return set_error(MCMCHIP_EINVAL, "null output");
+
+    bool mfma_ok = t->xt && !a->debug;
+    bool mfma = (a->path == MCMCHIP_PATH_MFMA) || (a->path == MCMCHIP_PATH_AUTO && mfma_ok && t->n >= 4096 && nchain >= 64);
+    if (mfma && !mfma_ok) return set_error(MCMCHIP_EINVAL, "MFMA path needs a logistic descriptor with d <= %d and debug = FALSE", MCMCHIP_MFMA_MAXD);
+
+    hipStream_t s = dc->stream;
+    const int dp = a->device_ptrs;
+    InBuf init, scale, outmap, z, u;
+    OutBuf accept, batch, final_, accb, dcur, dprop, dz, dlg, du, dacc;
+    HIP_TRY(init.set(a->initial, (size_t)nchain * d * 8, dp, s));
+    HIP_TRY(scale.set(a->scale, slen * 8, 0, s));            // scale and the index map are tiny host arrays
+    HIP_TRY(outmap.set(map.data(), map.size() * sizeof(int), 0, s));
+    if (a->rng_mode == MCMCHIP_RNG_INJECTED) {
+        HIP_TRY(z.set(a->z, (size_t)nchain * niter * d * 8, dp, s));
+        HIP_TRY(u.set(a->u, (size_t)nchain * niter * 8, dp, s));
+    }
+    HIP_TRY(accept.set(o->accept, (size_t)nchain * 8, dp));
+    HIP_TRY(batch.set(o->batch, (size_t)nchain * a->nbatch * (nout ? nout : 1) * 8, dp));
+    HIP_TRY(final_.set(o->final, (size_t)nchain * d * 8, dp));
+    HIP_TRY(accb.set(o->accept_batch, (size_t)nchain * a->nbatch * 8, dp));
+    if (a->debug) {
+        HIP_TRY(dcur.set(o->current, (size_t)nchain * niter * d * 8, dp));
+        HIP_TRY(dprop.set(o->proposal, (size_t)nchain * niter * d * 8, dp));
+        HIP_TRY(dz.set(o->z, (size_t)nchain * niter * d * 8, dp));
+        HIP_TRY(dlg.set(o->log_green, (size_t)nchain * niter * 8, dp));
+        HIP_TRY(du.set(o->u, (size_t)nchain * niter * 8, dp));
+        HIP_TRY(dacc.set(o->debug_accept, (size_t)nchain * niter * 4, dp));
+    }
+    HIP_TRY(hipMemsetAsync(dc->d_flag, 0, sizeof(int), s));
+
+    MetropDev p;
+    memset(&p, 0, sizeof p);
+    p.kind = t->kind; p.d = d; p.n = t->n; p.x = t->x; p.y = t->y; p.par = t->par; p.npar = t->npar;
+    p.prior_c = t->prior_c;
+    p.nchain = nchain; p.nbatch = a->nbatch; p.blen = a->blen; p.nspac = a->nspac;
+    p.scale_kind = a->scale_kind; p.scale = scale.as<double>();
+    p.nout = nout; p.sq_from = sq_from; p.out_map = outmap.as<int>();
+    p.rng_mode = a->rng_mode; p.z = z.as<double>(); p.u = u.as<double>();
+    p.seed = a->seed; p.chain_offset = a->chain_offset; p.iter_offset = a->iter_offset;
+    p.debug = a->debug;
+    p.initial = init.as<double>();
+    p.final_ = final_.as<double>(); p.accept = accept.as<double>(); p.batch = batch.as<double>();
+    p.accept_batch = accb.as<double>();
+    p.dbg_current = dcur.as<double>(); p.dbg_proposal = dprop.as<double>(); p.dbg_z = dz.as<double>();
+    p.dbg_lg = dlg.as<double>(); p.dbg_u = du.as<double>(); p.dbg_accept = dacc.as<int>();
+    p.flag = dc->d_flag;
+
+    int rc;
+    if (mfma) {
+        rc = run_metrop_mfma(t, p, dc);
+    } else {
+        timing_reset("metrop_stream_kernel");
+        timing_begin(s);
+        rc = launch_metrop_stream(p, s);
+        timing_end(s);
+    }
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    rc = check_flag(dc, false);     // synchronises; device buffers are released by the destructors
+    if (rc) return rc;
+    HIP_TRY(accept.finish(s));
+    HIP_TRY(batch.finish(s));
+    HIP_TRY(final_.finish(s));
+    HIP_TRY(accb.finish(s));
+    if (a->debug) {
+        HIP_TRY(dcur.finish(s)); HIP_TRY(dprop.finish(s)); HIP_TRY(dz.finish(s));
+        HIP_TRY(dlg.finish(s)); HIP_TRY(du.finish(s)); HIP_TRY(dacc.finish(s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    o->nout = nout;
+    o->iter_offset_out = a->iter_offset + (uint64_t)niter;
+    o->path_used = mfma ? MCMCHIP_PATH_MFMA : MCMCHIP_PATH_STREAM;
+    return MCMCHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchip_temper_out *o)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!t || !a || !o) return set_error(MCMCHIP_EINVAL, "null argument");
+    if (!is_temper_kind(t->kind)) return set_error(MCMCHIP_EINVAL, "descriptor kind %d is not a tempering target", t->kind);
+    const int k = a->ncomp, p = t->d;
+    // temper.c:29-95 checks
+    if (!a->neighbors) return set_error(MCMCHIP_EINVAL, "argument \"neighbors\" must be logical");
+    if (k <= 1) return set_error(MCMCHIP_EINVAL, "must have at least two components");
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++)
+            if ((a->neighbors[i + k * j] != 0) != (a->neighbors[j + k * i] != 0))
+                return set_error(MCMCHIP_EINVAL, "argument \"neighbors\" must be symmetric matrix");
+    if (!a->initial) return set_error(MCMCHIP_EINVAL, "argument \"initial\" must be real");
+    if (a->nens <= 0) return set_error(MCMCHIP_EINVAL, "nens must be positive");
+    if (a->nbatch <= 0) return set_error(MCMCHIP_EINVAL, "argument \"nbatch\" must be positive");
+    if (a->blen <= 0) return set_error(MCMCHIP_EINVAL, "argument \"blen\" must be positive");
+    if (a->nspac <= 0) return set_error(MCMCHIP_EINVAL, "argument \"nspac\" must be positive");
+    if (t->kind == MCMCHIP_T_WITCH && t->npar != k) return set_error(MCMCHIP_EINVAL, "witch descriptor needs one bound per component");
+    const long nens = a->nens;
+    const int nstate = a->parallel ? k * p : p + 1;
+    const long niter = (long)a->nbatch * a->blen * a->nspac;
+    if (!a->device_ptrs) {
+        for (size_t i = 0; i < (size_t)nens * nstate; i++)
+            if (!isfinite(a->initial[i])) return set_error(MCMCHIP_EINVAL, "argument \"initial\" must have all elements finite");
+        if (!a->parallel)
+            for (long e = 0; e < nens; e++) {
+                double ri = a->initial[(size_t)e * nstate];
+                int i = (int)ri;
+                if (i != ri) return set_error(MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be integer in serial case");
+                if (i <= 0 || i > k) return set_error(MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be in 1, ..., k in serial case");
+            }
+    }
+    size_t slen1;
+    switch (a->scale_kind & 7) {
+    case MCMCHIP_SCALE_CONSTANT: slen1 = 1; break;
+    case MCMCHIP_SCALE_DIAGONAL: slen1 = p; break;
+    case MCMCHIP_SCALE_FULL: slen1 = (size_t)p * p; break;
+    default: return set_error(MCMCHIP_EINVAL, "scale not matrix, scalar, or vector of length k");
+    }
+    size_t slen = (a->scale_kind & MCMCHIP_SCALE_LIST) ? slen1 * k : slen1;
+    if (!a->scale) return set_error(MCMCHIP_EINVAL, "scale not type double");
+    for (size_t i = 0; i < slen; i++)
+        if (!isfinite(a->scale[i])) return set_error(MCMCHIP_EINVAL, "scale has non-finite element");
+    if (a->rng_mode == MCMCHIP_RNG_INJECTED) {
+        if (!a->unif || !a->norm) return set_error(MCMCHIP_EINVAL, "injected random streams unif and norm are required in parity mode");
+    } else if (a->rng_mode != MCMCHIP_RNG_PHILOX) {
+        return set_error(MCMCHIP_EINVAL, "unknown rng_mode %d", a->rng_mode);
+    }
+    if (!o->batch || !o->acceptx || !o->accepti || !o->final || (!a->parallel && !o->ibatch))
+        return set_error(MCMCHIP_EINVAL, "null output");
+
+    hipStream_t s = dc->stream;
+    const int dp = a->device_ptrs;
+    const int nout = a->parallel ? k * p : p;
+    InBuf init, scale, nbrs, unif, norm;
+    OutBuf batch, ibatch, acceptx, accepti, final_;
+    HIP_TRY(init.set(a->initial, (size_t)nens * nstate * 8, dp, s));
+    HIP_TRY(scale.set(a->scale, slen * 8, 0, s));
+    HIP_TRY(nbrs.set(a->neighbors, (size_t)k * k * sizeof(int), 0, s));
+    if (a->rng_mode == MCMCHIP_RNG_INJECTED) {
+        HIP_TRY(unif.set(a->unif, (size_t)nens * niter * 4 * 8, dp, s));
+        HIP_TRY(norm.set(a->norm, (size_t)nens * niter * p * 8, dp, s));
+    }
+    HIP_TRY(batch.set(o->batch, (size_t)nens * a->nbatch * nout * 8, dp));
+    if (!a->parallel) HIP_TRY(ibatch.set(o->ibatch, (size_t)nens * a->nbatch * k * 8, dp));
+    HIP_TRY(acceptx.set(o->acceptx, (size_t)nens * k * 8, dp));
+    HIP_TRY(accepti.set(o->accepti, (size_t)nens * k * k * 8, dp));
+    HIP_TRY(final_.set(o->final, (size_t)nens * nstate * 8, dp));
+    HIP_TRY(hipMemsetAsync(dc->d_flag, 0, sizeof(int), s));
+
+    TemperDev q;
+    memset(&q, 0, sizeof q);
+    q.kind = t->kind; q.p = p; q.par = t->par; q.npar = t->npar;
+    q.nens = nens; q.k = k; q.parallel = a->parallel; q.nbatch = a->nbatch; q.blen = a->blen; q.nspac = a->nspac;
+    q.neighbors = nbrs.as<int>(); q.initial = init.as<double>();
+    q.scale_kind = a->scale_kind; q.scale = scale.as<double>();
+    q.rng_mode = a->rng_mode; q.unif = unif.as<double>(); q.norm = norm.as<double>();
+    q.seed = a->seed; q.ens_offset = a->ens_offset; q.iter_offset = a->iter_offset;
+    q.batch = batch.as<double>(); q.ibatch = ibatch.as<double>(); q.acceptx = acceptx.as<double>();
+    q.accepti = accepti.as<double>(); q.final_ = final_.as<double>();
+    q.flag = dc->d_flag;
+    timing_reset("temper_kernel");
+    timing_begin(s);
+    int rc = launch_temper(q, s);
+    timing_end(s);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    rc = check_flag(dc, true);
+    if (rc) return rc;
+    HIP_TRY(batch.finish(s));
+    if (!a->parallel) HIP_TRY(ibatch.finish(s));
+    HIP_TRY(acceptx.finish(s));
+    HIP_TRY(accepti.finish(s));
+    HIP_TRY(final_.finish(s));
+    HIP_TRY(hipStreamSynchronize(s));
+    o->iter_offset_out = a->iter_offset + (uint64_t)niter;
+    return MCMCHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs, int64_t cap,
+                    int64_t *n_out, double *gamma0, double *Gamma_pos, double *Gamma_dec,
+                    double *Gamma_con, double *var_pos, double *var_dec, double *var_con)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!x) return set_error(MCMCHIP_EINVAL, "argument must be numeric");
+    if (len <= 0 || ncol <= 0 || cap <= 0 || !n_out || !gamma0 || !Gamma_pos || !Gamma_dec || !Gamma_con ||
+        !var_pos || !var_dec || !var_con)
+        return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_initseq");
+    if (!device_ptrs)
+        for (size_t i = 0; i < (size_t)len * ncol; i++)
+            if (!isfinite(x[i])) return set_error(MCMCHIP_EINVAL, "all elements of argument must be finite");
+    InBuf in;
+    HIP_TRY(in.set(x, (size_t)len * ncol * 8, device_ptrs, dc->stream));
+    return run_initseq(in.as<double>(), len, ncol, cap, (long *)n_out, gamma0, Gamma_pos, Gamma_dec,
+                       Gamma_con, var_pos, var_dec, var_con, dc);
+}
+
+int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
+                 int32_t nocalc, int device_ptrs)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!x || !mean || !var || n <= 0 || p <= 0 || len <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_olbm");
+    if (len > n) return set_error(MCMCHIP_EINVAL, "len > n\n");
+    InBuf in;
+    HIP_TRY(in.set(x, (size_t)n * p * 8, device_ptrs, dc->stream));
+    return run_olbm(in.as<double>(), n, p, len, mean, var, nocalc, dc);
+}
+
+}  // extern "C"

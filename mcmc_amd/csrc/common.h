@@ -1,0 +1,129 @@
+// common.h -- shared host-side context, error plumbing and small device helpers of libmcmchip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/mcmchip.h"
+#include "softplus.h"
+
+#define MCMCHIP_MAX_DEVICES 16
+#define MCMCHIP_MFMA_MAXD 64
+
+struct DeviceCtx {
+    bool inited = false;
+    hipStream_t stream = nullptr;
+    SoftplusTables *d_tables = nullptr;  // softplus tables in HBM
+    int *d_flag = nullptr;               // error flag word shared by the kernels
+    int num_cu = 256;
+};
+
+// per-process state (one process per GPU in the multi-GPU launch, but any device may be selected)
+struct LibCtx {
+    int device = -1;
+    DeviceCtx dev[MCMCHIP_MAX_DEVICES];
+    // timing of the dominant kernel of the last call (HIP events on our stream)
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    int ev_used = 0;
+    char ev_name[64] = {0};
+};
+
+LibCtx &lib_ctx();
+DeviceCtx *cur_dev();  // nullptr (and error set) when mcmchip_init has not succeeded
+
+int set_error(int code, const char *fmt, ...);
+void clear_error();
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return set_error(MCMCHIP_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e__),    \
+                             __FILE__, __LINE__);                                              \
+    } while (0)
+
+// device buffer freed at scope exit (outputs staged through HBM when device_ptrs == 0)
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n)
+    {
+        bytes = n;
+        return hipMalloc(&p, n ? n : 8);
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// bring an input into HBM: either the caller's device pointer as-is, or a staged copy
+struct InBuf {
+    DevBuf own;
+    const void *ptr = nullptr;
+    hipError_t set(const void *src, size_t bytes, int device_ptrs, hipStream_t s)
+    {
+        if (!src || bytes == 0) { ptr = nullptr; return hipSuccess; }
+        if (device_ptrs) { ptr = src; return hipSuccess; }
+        hipError_t e = own.alloc(bytes);
+        if (e != hipSuccess) return e;
+        ptr = own.p;
+        return hipMemcpyAsync(own.p, src, bytes, hipMemcpyHostToDevice, s);
+    }
+    template <class T> const T *as() const { return (const T *)ptr; }
+};
+
+// an output: the caller's device pointer, or a device staging buffer copied back at the end
+struct OutBuf {
+    DevBuf own;
+    void *ptr = nullptr;
+    void *host = nullptr;
+    size_t bytes = 0;
+    hipError_t set(void *dst, size_t n, int device_ptrs)
+    {
+        bytes = n;
+        if (!dst) { ptr = nullptr; return hipSuccess; }
+        if (device_ptrs) { ptr = dst; return hipSuccess; }
+        host = dst;
+        hipError_t e = own.alloc(n);
+        ptr = own.p;
+        return e;
+    }
+    hipError_t finish(hipStream_t s)
+    {
+        if (host && ptr && bytes) return hipMemcpyAsync(host, ptr, bytes, hipMemcpyDeviceToHost, s);
+        return hipSuccess;
+    }
+    template <class T> T *as() { return (T *)ptr; }
+};
+
+// error flag bits written by kernels
+#define FLAG_NEGINF_INIT 1  // log unnormalized density -Inf at initial state (metrop.c:196-197)
+#define FLAG_POSINF 2       // logh: func returned +Inf (metrop.c:317-318)
+#define FLAG_NAN 4          // logh: func returned NA or NaN (metrop.c:319-320)
+#define FLAG_HASTINGS 8     // temper: log hastings ratio +Inf or NaN (temper.c:578-580)
+
+struct mcmchip_target {
+    int kind = 0, d = 0;
+    int64_t n = 0;
+    double prior_c = 0;
+    double *x = nullptr;    // n x d row-major (logistic kinds)
+    double *y = nullptr;    // n
+    double *par = nullptr;
+    int64_t npar = 0;
+    std::vector<double> host_par;
+    // fp64 MFMA layout (logistic kind only): sign-folded, zero-padded, fragment-major tiles
+    int dpad = 0, ksteps = 0;
+    int64_t ntiles = 0;     // 16-observation tiles (padded up to a multiple of MFMA_TILES_PER_CHUNK)
+    int64_t npad_rows = 0;  // zero rows appended (each contributes exactly -L(0) = -ln 2)
+    double *xt = nullptr;
+    int device = 0;
+};
+
+// kernel timing hooks (metrop_mfma.hip uses them around the log-density launches)
+void timing_reset(const char *name);
+void timing_begin(hipStream_t s);
+void timing_end(hipStream_t s);

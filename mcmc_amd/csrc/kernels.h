@@ -1,0 +1,68 @@
+// kernels.h -- internal launch interfaces between the C-ABI glue (capi.hip) and the kernel files.
+#pragma once
+#include "common.h"
+
+// everything the samplers need, with all pointers already in HBM
+struct MetropDev {
+    // target
+    int kind, d;
+    long n;
+    const double *x, *y, *par;
+    long npar;
+    double prior_c;
+    // run shape
+    long nchain;
+    int nbatch, blen, nspac;
+    int scale_kind;
+    const double *scale;
+    int nout, sq_from;        // g(x)_k = x[out_map[k]] (squared when k >= sq_from)
+    const int *out_map;
+    int rng_mode;
+    const double *z, *u;      // injected streams
+    unsigned long long seed, chain_offset, iter_offset;
+    int debug;
+    // chain-major inputs/outputs
+    const double *initial;
+    double *final_, *accept, *batch, *accept_batch;
+    double *dbg_current, *dbg_proposal, *dbg_z, *dbg_lg, *dbg_u;
+    int *dbg_accept;
+    int *flag;
+};
+
+// metrop_stream.hip: one persistent launch, G lanes per chain, whole nbatch*blen*nspac loop in-kernel
+int launch_metrop_stream(const MetropDev &p, hipStream_t s);
+// log density of nchain states (chain-major; temper kinds: (i, theta))
+int launch_logdens_stream(const mcmchip_target *t, const double *states, long nchain, double *out,
+                          hipStream_t s);
+
+// metrop_mfma.hip: lockstep iterations, fp64 MFMA X.Theta contraction + update kernel per iteration
+int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc);
+int launch_logdens_mfma(const mcmchip_target *t, const double *states, long nchain, double *out,
+                        DeviceCtx *dc);
+int build_mfma_tiles(mcmchip_target *t, hipStream_t s);
+
+// temper.hip
+struct TemperDev {
+    int kind, p;              // target kind, dimension of theta
+    const double *par;
+    long npar;
+    long nens;
+    int k, parallel, nbatch, blen, nspac;
+    const int *neighbors;     // k x k
+    const double *initial;
+    int scale_kind;
+    const double *scale;
+    int rng_mode;
+    const double *unif, *norm;
+    unsigned long long seed, ens_offset, iter_offset;
+    double *batch, *ibatch, *acceptx, *accepti, *final_;
+    int *flag;
+};
+int launch_temper(const TemperDev &p, hipStream_t s);
+
+// diag.hip
+int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0,
+                double *Gpos, double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon,
+                DeviceCtx *dc);
+int run_olbm(const double *x, long n, int p, long len, double *mean, double *var, int nocalc,
+             DeviceCtx *dc);

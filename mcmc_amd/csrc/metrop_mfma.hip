@@ -1,0 +1,462 @@
+// metrop_mfma.hip -- batched random-walk Metropolis, fp64 MFMA path (large n, many chains).
+//
+// What it replaces: the same loop nest as metrop_stream.hip (metrop.c:199-285), but here the
+// log density of the logistic posterior (vignettes/demo.Rnw:59-65) dominates: for C lockstep
+// chains eta = X (n x d) . Theta (d x C) is a genuine dense fp64 contraction, 2*n*d flop per
+// chain-iteration, followed by n softplus evaluations per chain.
+//
+// Per Metropolis iteration two kernels run on the library stream:
+//   logdens_mfma_kernel  grid (C/(64*NC), nsplit): a workgroup of 4 wavefronts owns 64*NC chains
+//       per wave-quarter... precisely: wave w owns NC 16-chain tiles whose Theta fragments stay
+//       in VGPRs for the whole launch (loop invariant); the workgroup streams its share of the
+//       observation tiles of X through a double-buffered LDS ring filled by LDS-DMA
+//       (global_load_lds, 16 B/lane), so X is read once per workgroup from HBM/L2 and each
+//       16-observation tile feeds 16*NC v_mfma_f64_16x16x4_f64 per wave.  The accumulator tile
+//       (4 observations x 1 chain per lane) goes straight through the softplus epilogue
+//       (softplus.h, 28 fp64 VALU ops) and into a per-lane running sum: eta never leaves
+//       registers.  The epilogue of tile t is issued next to the MFMAs of tile t+1.
+//   metrop_update_kernel one lane per chain: fixed-order sum of the nsplit partials (bitwise
+//       reproducible, independent of the number of GPUs), prior term, accept rule
+//       (metrop.c:225-235), state/batch-means bookkeeping, Philox normals and the next proposal.
+//
+// HBM layout: X is stored once per target as sign-folded fragment-major tiles
+//   xt[tile][kstep][lane] = s_row * X[16*tile + (lane&15)][4*kstep + (lane>>4)],  s = +1 (y==1) / -1 (y==0)
+// so that min(s*eta,0) - L(|eta|) needs no label in the loop and a wave's A fragment is one
+// coalesced 512-B row.  State, proposal and batch accumulators are dimension-major
+// ([d][C], "SoA") so that both the per-chain update kernel and the B-fragment loads coalesce.
+//
+// Roofline: fp64 MFMA.  Algorithmic flops per launch = 2 * n * d * C.
+#include "kernels.h"
+#include "philox.h"
+
+#define MFMA_TC 4          // observation tiles per LDS chunk
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+__global__ void tile_x_kernel(const double *__restrict__ x, const double *__restrict__ y, long n, int d,
+                              int ksteps, long ntiles, double *__restrict__ xt)
+{
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = ntiles * ksteps * 64;
+    if (idx >= total) return;
+    int lane = (int)(idx & 63);
+    long tk = idx >> 6;
+    int ks = (int)(tk % ksteps);
+    long t = tk / ksteps;
+    long row = t * 16 + (lane & 15);
+    int col = 4 * ks + (lane >> 4);
+    double v = 0.0;
+    if (row < n && col < d) {
+        v = x[(size_t)row * d + col];
+        if (y[row] != 1.0) v = -v;
+    }
+    xt[idx] = v;
+}
+
+int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
+{
+    t->dpad = ((t->d + 7) / 8) * 8;
+    if (t->dpad < 8) t->dpad = 8;
+    t->ksteps = t->dpad / 4;
+    long tiles = (t->n + 15) / 16;
+    tiles = ((tiles + MFMA_TC - 1) / MFMA_TC) * MFMA_TC;
+    t->ntiles = tiles;
+    t->npad_rows = tiles * 16 - t->n;
+    size_t bytes = (size_t)tiles * t->ksteps * 64 * sizeof(double);
+    HIP_TRY(hipMalloc((void **)&t->xt, bytes));
+    long total = tiles * t->ksteps * 64;
+    hipLaunchKernelGGL(tile_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t->x, t->y,
+                       (long)t->n, t->d, t->ksteps, tiles, t->xt);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int KS, int NC>
+__device__ __forceinline__ void epilogue_tile(const double4_t (&acc)[NC], double (&sum)[NC],
+                                              const double *sExp, const double *sLog)
+{
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double eta = acc[c][r];
+            const double L = softplus_neg(fabs(eta), sExp, sLog);
+            sum[c] += fmin(eta, 0.0) - L;
+        }
+    }
+}
+
+template <int KS, int NC>
+__global__ __launch_bounds__(256, 1) void logdens_mfma_kernel(const double *__restrict__ xt,
+                                                              const double *__restrict__ prop, long ldc,
+                                                              double *__restrict__ partial,
+                                                              long tiles_per_split, long ntiles,
+                                                              const SoftplusTables *__restrict__ tab)
+{
+    constexpr int CHUNK = MFMA_TC * KS * 64;          // doubles per LDS buffer
+    __shared__ __attribute__((aligned(16))) double smem[2 * CHUNK + SP_EXP_N + 2 * SP_LOG_N];
+    double *sX = smem;
+    double *sExp = smem + 2 * CHUNK;
+    double *sLog = sExp + SP_EXP_N;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < SP_EXP_N; i += 256) sExp[i] = tab->expT[i];
+    for (int i = threadIdx.x; i < 2 * SP_LOG_N; i += 256) sLog[i] = tab->logT[i];
+
+    // loop-invariant B fragments: Theta[k = 4ks + (lane>>4)][chain = chain0 + 16c + (lane&15)]
+    const long chain0 = ((long)blockIdx.x * 4 + wave) * 16 * NC;
+    double b[KS][NC];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            b[ks][c] = prop[(size_t)(4 * ks + (lane >> 4)) * ldc + chain0 + 16 * c + (lane & 15)];
+
+    const long t0 = (long)blockIdx.y * tiles_per_split;
+    long t1 = t0 + tiles_per_split;
+    if (t1 > ntiles) t1 = ntiles;
+    const long nchunks = (t1 - t0) / MFMA_TC;
+    const double *gsrc = xt + (size_t)t0 * KS * 64;
+
+    // LDS-DMA: each wave moves its quarter of a chunk, 1 KiB (64 lanes x 16 B) per instruction
+    constexpr int PER_WAVE = CHUNK / 4;               // doubles
+    constexpr int NINST = PER_WAVE / 128;
+    auto stage = [&](long chunk, int buf) {
+        const double *g = gsrc + (size_t)chunk * CHUNK + wave * PER_WAVE + lane * 2;
+        double *l = sX + buf * CHUNK + wave * PER_WAVE;
+#pragma unroll
+        for (int i = 0; i < NINST; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i * 128),
+                                             (__attribute__((address_space(3))) void *)(l + i * 128), 16, 0, 0);
+    };
+
+    double sum[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) sum[c] = 0.0;
+    double4_t prev[NC];
+
+    if (nchunks > 0) stage(0, 0);
+    __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the tables
+
+    for (long ch = 0; ch < nchunks; ch++) {
+        const int buf = (int)(ch & 1);
+        if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+        const double *xs = sX + buf * CHUNK + lane;
+#pragma unroll
+        for (int tt = 0; tt < MFMA_TC; tt++) {
+            double4_t acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const double a = xs[(tt * KS + ks) * 64];
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][c], acc[c], 0, 0, 0);
+            }
+            if (!(ch == 0 && tt == 0)) epilogue_tile<KS, NC>(prev, sum, sExp, sLog);
+#pragma unroll
+            for (int c = 0; c < NC; c++) prev[c] = acc[c];
+        }
+        __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
+    }
+    if (nchunks > 0) epilogue_tile<KS, NC>(prev, sum, sExp, sLog);
+
+    // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        double v = sum[c];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) partial[(size_t)blockIdx.y * ldc + chain0 + 16 * c + lane] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct UpdParams {
+    long nchain, ldc;
+    int d, dpad;
+    int nsplit;
+    double pad_term;        // npad_rows * ln 2 (each zero row contributes exactly -L(0))
+    double prior_c;
+    int nbatch, blen, nspac;
+    int scale_kind;
+    const double *scale;
+    int nout, sq_from;
+    const int *out_map;
+    int rng_mode;
+    const double *z, *u;
+    unsigned long long seed, chain_offset, iter_offset;
+    const double *partial;
+    double *state, *prop;   // [dpad][ldc]
+    double *cur, *acc, *acc_b, *buf;  // [ldc], [ldc], [ldc], [nout][ldc]
+    double *batch, *accept_batch, *accept, *final_;  // chain-major outputs
+    double *logdens_out;    // when non-null: just emit the log density (mcmchip_logdens)
+    int *flag;
+};
+
+__device__ __forceinline__ void make_proposal(const UpdParams &q, long c, long l_next)
+{
+    const int d = q.d;
+    const long ldc = q.ldc;
+    const long niter = (long)q.nbatch * q.blen * q.nspac;
+    double zl[MCMCHIP_MFMA_MAXD];
+    if (q.rng_mode == MCMCHIP_RNG_INJECTED) {
+        const double *zp = q.z + ((size_t)c * niter + l_next) * d;
+        for (int j = 0; j < d; j++) zl[j] = zp[j];
+    } else {
+        for (int j = 0; j < d; j += 2) {
+            double za, zb;
+            philox_n2(q.seed, PHILOX_TAG_METROP, q.chain_offset + (unsigned long long)c,
+                      q.iter_offset + (unsigned long long)l_next, (uint32_t)(j / 2), za, zb);
+            zl[j] = za;
+            if (j + 1 < d) zl[j + 1] = zb;
+        }
+    }
+    if (q.scale_kind == MCMCHIP_SCALE_CONSTANT) {
+        const double s0 = q.scale[0];
+        for (int j = 0; j < d; j++)
+            q.prop[(size_t)j * ldc + c] = __dadd_rn(q.state[(size_t)j * ldc + c], __dmul_rn(s0, zl[j]));
+    } else if (q.scale_kind == MCMCHIP_SCALE_DIAGONAL) {
+        for (int j = 0; j < d; j++)
+            q.prop[(size_t)j * ldc + c] = __dadd_rn(q.state[(size_t)j * ldc + c], __dmul_rn(q.scale[j], zl[j]));
+    } else {
+        for (int j = 0; j < d; j++) {
+            double a = q.state[(size_t)j * ldc + c];
+            for (int i = 0; i < d; i++) a = __dadd_rn(a, __dmul_rn(q.scale[j + (size_t)d * i], zl[i]));
+            q.prop[(size_t)j * ldc + c] = a;
+        }
+    }
+}
+
+// l == -1: initial state (prop holds a copy of the state): record cur, draw the first proposal
+__global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= q.nchain) return;
+    const int d = q.d;
+    const long ldc = q.ldc;
+    double ly = 0.0;
+    for (int s = 0; s < q.nsplit; s++) ly += q.partial[(size_t)s * ldc + c];
+    ly += q.pad_term;
+    double ss = 0.0;
+    for (int j = 0; j < d; j++) { const double v = q.prop[(size_t)j * ldc + c]; ss += v * v; }
+    ly -= ss * q.prior_c;
+    if (q.logdens_out) { q.logdens_out[c] = ly; return; }
+    if (ly == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+    else if (isnan(ly)) atomicOr(q.flag, FLAG_NAN);
+    const long niter = (long)q.nbatch * q.blen * q.nspac;
+    if (l < 0) {
+        if (ly == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+        q.cur[c] = ly;
+        q.acc[c] = 0.0;
+        q.acc_b[c] = 0.0;
+        for (int k = 0; k < q.nout; k++) q.buf[(size_t)k * ldc + c] = 0.0;
+        make_proposal(q, c, 0);
+        return;
+    }
+    const double cur = q.cur[c];
+    bool accept = false;
+    if (ly != -INFINITY && !isnan(ly)) {       // metrop.c:225-235
+        if (ly > cur) {
+            accept = true;
+        } else {
+            const double green = exp(ly - cur);
+            double u, ub;
+            if (q.rng_mode == MCMCHIP_RNG_INJECTED) u = q.u[(size_t)c * niter + l];
+            else philox_u2(q.seed, PHILOX_TAG_METROP, q.chain_offset + (unsigned long long)c,
+                           q.iter_offset + (unsigned long long)l, PHILOX_BLOCK_UNIF, u, ub);
+            accept = u < green;
+        }
+    }
+    if (accept) {
+        for (int j = 0; j < d; j++) q.state[(size_t)j * ldc + c] = q.prop[(size_t)j * ldc + c];
+        q.cur[c] = ly;
+        q.acc[c] += 1.0;
+        q.acc_b[c] += 1.0;
+    }
+    const int is = (int)(l % q.nspac);
+    const long lb = l / q.nspac;
+    const int jb = (int)(lb % q.blen);
+    const long ib = lb / q.blen;
+    if (is == q.nspac - 1) {                   // metrop.c:273-275
+        for (int k = 0; k < q.nout; k++) {
+            double v = q.state[(size_t)q.out_map[k] * ldc + c];
+            if (k >= q.sq_from) v = __dmul_rn(v, v);
+            q.buf[(size_t)k * ldc + c] = __dadd_rn(q.buf[(size_t)k * ldc + c], v);
+        }
+        if (jb == q.blen - 1) {                // metrop.c:279-283
+            for (int k = 0; k < q.nout; k++) {
+                q.batch[((size_t)c * q.nbatch + ib) * q.nout + k] = q.buf[(size_t)k * ldc + c] / q.blen;
+                q.buf[(size_t)k * ldc + c] = 0.0;
+            }
+            q.accept_batch[(size_t)c * q.nbatch + ib] = q.acc_b[c] / ((double)q.blen * q.nspac);
+            q.acc_b[c] = 0.0;
+        }
+    }
+    if (l + 1 < niter) {
+        make_proposal(q, c, l + 1);
+    } else {
+        q.accept[c] = q.acc[c] / (double)niter;
+        for (int j = 0; j < d; j++) q.final_[(size_t)c * d + j] = q.state[(size_t)j * ldc + c];
+    }
+}
+
+// chain-major [C][d] -> dimension-major [dpad][ldc], zero padding (both state and prop)
+__global__ void soa_init_kernel(const double *__restrict__ init, long nchain, int d, int dpad, long ldc,
+                                double *__restrict__ state, double *__restrict__ prop)
+{
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)dpad * ldc) return;
+    long c = idx % ldc;
+    int j = (int)(idx / ldc);
+    double v = (c < nchain && j < d) ? init[(size_t)c * d + j] : 0.0;
+    state[idx] = v;
+    prop[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct MfmaPlan {
+    int ks, nc;
+    long ldc, chain_blocks;
+    int nsplit;
+    long tiles_per_split;
+};
+
+static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
+{
+    MfmaPlan pl;
+    pl.ks = t->ksteps;
+    pl.nc = (t->ksteps <= 8) ? 4 : 4;
+    long per_wg = 64L * pl.nc;
+    pl.chain_blocks = (nchain + per_wg - 1) / per_wg;
+    pl.ldc = pl.chain_blocks * per_wg;
+    long chunks = t->ntiles / MFMA_TC;
+    // enough workgroups for >= 2 waves of the chip, but keep >= 8 chunks per workgroup so the
+    // B-fragment preload and the pipeline fill amortise
+    long want = (2L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;
+    if (want < 1) want = 1;
+    long maxsplit = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (want > maxsplit) want = maxsplit;
+    if (want > 64) want = 64;
+    long cps = (chunks + want - 1) / want;     // chunks per split
+    pl.nsplit = (int)((chunks + cps - 1) / cps);
+    pl.tiles_per_split = cps * MFMA_TC;
+    return pl;
+}
+
+template <int KS>
+static void launch_ld(const MfmaPlan &pl, const mcmchip_target *t, const double *prop, double *partial,
+                      DeviceCtx *dc)
+{
+    dim3 grid((unsigned)pl.chain_blocks, (unsigned)pl.nsplit), block(256);
+    hipLaunchKernelGGL((logdens_mfma_kernel<KS, 4>), grid, block, 0, dc->stream, t->xt, prop, pl.ldc, partial,
+                       pl.tiles_per_split, t->ntiles, dc->d_tables);
+}
+
+static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const double *prop, double *partial,
+                          DeviceCtx *dc)
+{
+    switch (pl.ks) {
+    case 2: launch_ld<2>(pl, t, prop, partial, dc); break;
+    case 4: launch_ld<4>(pl, t, prop, partial, dc); break;
+    case 6: launch_ld<6>(pl, t, prop, partial, dc); break;
+    case 8: launch_ld<8>(pl, t, prop, partial, dc); break;
+    case 10: launch_ld<10>(pl, t, prop, partial, dc); break;
+    case 12: launch_ld<12>(pl, t, prop, partial, dc); break;
+    case 14: launch_ld<14>(pl, t, prop, partial, dc); break;
+    case 16: launch_ld<16>(pl, t, prop, partial, dc); break;
+    default: return set_error(MCMCHIP_EINVAL, "MFMA path supports d <= %d", MCMCHIP_MFMA_MAXD);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
+int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
+{
+    if (!t->xt) return set_error(MCMCHIP_EINVAL, "target has no MFMA tiles (not a logistic target)");
+    if (p.debug) return set_error(MCMCHIP_EINVAL, "debug trace is only available on the stream path");
+    hipStream_t s = dc->stream;
+    MfmaPlan pl = make_plan(t, p.nchain, dc->num_cu);
+    const long ldc = pl.ldc;
+    DevBuf state, prop, partial, cur, acc, acc_b, buf;
+    HIP_TRY(state.alloc((size_t)t->dpad * ldc * 8));
+    HIP_TRY(prop.alloc((size_t)t->dpad * ldc * 8));
+    HIP_TRY(partial.alloc((size_t)pl.nsplit * ldc * 8));
+    HIP_TRY(cur.alloc((size_t)ldc * 8));
+    HIP_TRY(acc.alloc((size_t)ldc * 8));
+    HIP_TRY(acc_b.alloc((size_t)ldc * 8));
+    HIP_TRY(buf.alloc((size_t)p.nout * ldc * 8));
+
+    long total = (long)t->dpad * ldc;
+    hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.initial,
+                       p.nchain, t->d, t->dpad, ldc, state.as<double>(), prop.as<double>());
+    HIP_TRY(hipGetLastError());
+
+    UpdParams q;
+    memset(&q, 0, sizeof q);
+    q.nchain = p.nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nsplit = pl.nsplit;
+    q.pad_term = (double)t->npad_rows * 0.6931471805599453;
+    q.prior_c = t->prior_c;
+    q.nbatch = p.nbatch; q.blen = p.blen; q.nspac = p.nspac;
+    q.scale_kind = p.scale_kind; q.scale = p.scale;
+    q.nout = p.nout; q.sq_from = p.sq_from; q.out_map = p.out_map;
+    q.rng_mode = p.rng_mode; q.z = p.z; q.u = p.u;
+    q.seed = p.seed; q.chain_offset = p.chain_offset; q.iter_offset = p.iter_offset;
+    q.partial = partial.as<double>();
+    q.state = state.as<double>(); q.prop = prop.as<double>();
+    q.cur = cur.as<double>(); q.acc = acc.as<double>(); q.acc_b = acc_b.as<double>(); q.buf = buf.as<double>();
+    q.batch = p.batch; q.accept_batch = p.accept_batch; q.accept = p.accept; q.final_ = p.final_;
+    q.logdens_out = nullptr;
+    q.flag = p.flag;
+
+    const long niter = (long)p.nbatch * p.blen * p.nspac;
+    dim3 ugrid((unsigned)((p.nchain + 255) / 256)), ublock(256);
+    timing_reset("logdens_mfma_kernel");
+    for (long l = -1; l < niter; l++) {
+        timing_begin(s);
+        int rc = launch_logdens(pl, t, prop.as<double>(), partial.as<double>(), dc);
+        timing_end(s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(metrop_update_kernel, ugrid, ublock, 0, s, q, l);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));   // the scratch buffers above are freed at scope exit
+    return MCMCHIP_OK;
+}
+
+int launch_logdens_mfma(const mcmchip_target *t, const double *states, long nchain, double *out,
+                        DeviceCtx *dc)
+{
+    if (!t->xt) return set_error(MCMCHIP_EINVAL, "target has no MFMA tiles (not a logistic target)");
+    hipStream_t s = dc->stream;
+    MfmaPlan pl = make_plan(t, nchain, dc->num_cu);
+    const long ldc = pl.ldc;
+    DevBuf state, prop, partial;
+    HIP_TRY(state.alloc((size_t)t->dpad * ldc * 8));
+    HIP_TRY(prop.alloc((size_t)t->dpad * ldc * 8));
+    HIP_TRY(partial.alloc((size_t)pl.nsplit * ldc * 8));
+    long total = (long)t->dpad * ldc;
+    hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, states,
+                       nchain, t->d, t->dpad, ldc, state.as<double>(), prop.as<double>());
+    HIP_TRY(hipGetLastError());
+    timing_reset("logdens_mfma_kernel");
+    timing_begin(s);
+    int rc = launch_logdens(pl, t, prop.as<double>(), partial.as<double>(), dc);
+    timing_end(s);
+    if (rc) return rc;
+    UpdParams q;
+    memset(&q, 0, sizeof q);
+    q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nsplit = pl.nsplit;
+    q.pad_term = (double)t->npad_rows * 0.6931471805599453;
+    q.prior_c = t->prior_c;
+    q.nbatch = q.blen = q.nspac = 1;
+    q.partial = partial.as<double>();
+    q.state = state.as<double>(); q.prop = prop.as<double>();
+    q.logdens_out = out;
+    hipLaunchKernelGGL(metrop_update_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q, -1L);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return MCMCHIP_OK;
+}

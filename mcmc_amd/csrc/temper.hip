@@ -1,0 +1,272 @@
+// temper.hip -- serial and parallel tempering for `nens` independent ensembles.
+//
+// What it replaces: the loop nest of the reference's temper() (temper.c:517-887): per
+// iteration ONE elementary update -- with probability 1/2 a within-component random-walk
+// Metropolis step on one component (temper.c:547-675), else a swap of two neighbouring
+// components (parallel, 679-781) or a jump to a neighbour (serial, 783-845) -- plus batch
+// means (851-886) and the acceptance-rate tables (889-897).
+//
+// Mapping onto gfx950: one wavefront (a 64-thread workgroup) per ensemble.  The k x p state
+// matrix, the cached log densities (temper.c:123-124), the batch accumulator and the per-pair
+// acceptance counters all live in LDS, so a swap is two LDS row exchanges and nothing touches
+// HBM inside the iteration loop except injected random numbers in parity mode.  Control flow
+// is wave-uniform (every lane of the wave follows the same within/swap branch: no divergence);
+// the vector parts (normals, proposal, row swap, batch accumulation over k*p elements) are
+// spread over the lanes.  The path is latency-bound (a dependent chain Philox -> index ->
+// density -> exp -> compare per iteration), so throughput comes from running all ensembles
+// concurrently (1024 ensembles = 4 waves per CU).
+//
+// RNG draw order per iteration is the reference's: u_which, then u_choose
+// [, u_choose2 | normals], then u_hastings iff log Hastings < 0 (temper.c:584-587): a -Inf
+// proposal DOES draw and reject; equality accepts without a draw -- the opposite of metrop.
+#include "kernels.h"
+#include "philox.h"
+#include "targets.h"
+
+#define TEMPER_MAXP 16
+#define TEMPER_MAXK 64
+
+struct TemperLds {
+    int state, L, Y, Z, buf, ibuf, axn, axd, ain, aid, nn, nb, end;  // offsets in 8-byte words
+};
+
+__device__ __forceinline__ int pick1(double u, int m)
+{
+    int i = (int)trunc(m * u) + 1;   // temper.c:555-556
+    if (i > m) i--;
+    return i;
+}
+
+__global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, int maxnn)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long e = blockIdx.x;
+    const int k = q.k, p = q.p, par = q.parallel;
+    const int nstate = par ? k * p : p + 1;
+    const int nout = par ? k * p : p;
+    double *S = lds + lay.state, *L = lds + lay.L, *Y = lds + lay.Y, *Z = lds + lay.Z;
+    double *buf = lds + lay.buf, *ibuf = lds + lay.ibuf;
+    unsigned *axn = (unsigned *)(lds + lay.axn), *axd = (unsigned *)(lds + lay.axd);
+    unsigned *ain = (unsigned *)(lds + lay.ain), *aid = (unsigned *)(lds + lay.aid);
+    int *nn = (int *)(lds + lay.nn), *nb = (int *)(lds + lay.nb);
+
+    for (int i = lane; i < nstate; i += 64) S[i] = q.initial[(size_t)e * nstate + i];
+    for (int i = lane; i < k; i += 64) {
+        int c = 0;
+        for (int j = 0; j < k; j++)
+            if (q.neighbors[i + k * j]) nb[i * maxnn + c++] = j;   // ascending order (temper.c:504-510)
+        nn[i] = c;
+        axn[i] = axd[i] = 0;
+        ibuf[i] = 0.0;
+        for (int c2 = 0; c2 < maxnn; c2++) ain[i * maxnn + c2] = aid[i * maxnn + c2] = 0;
+    }
+    __syncthreads();
+    // cached log densities (temper.c:98-119)
+    if (par) {
+        for (int i = lane; i < k; i += 64) {
+            double th[TEMPER_MAXP];
+            for (int j = 0; j < p; j++) th[j] = S[i + k * j];
+            double v = lud_temper(q.kind, p, q.par, i + 1, th);
+            L[i] = v;
+            if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+            else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+            else if (isnan(v)) atomicOr(q.flag, FLAG_NAN);
+        }
+    } else {
+        for (int i = lane; i < k; i += 64) L[i] = NAN;
+        __syncthreads();
+        if (lane == 0) {
+            int i = (int)S[0];
+            double v = lud_temper(q.kind, p, q.par, i, S + 1);
+            L[i - 1] = v;
+            if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+            else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+            else if (isnan(v)) atomicOr(q.flag, FLAG_NAN);
+        }
+    }
+    __syncthreads();
+
+    const long niter = (long)q.nbatch * q.blen * q.nspac;
+    const unsigned long long gens = q.ens_offset + (unsigned long long)e;
+    const int sk = q.scale_kind & 7;
+    const int slen1 = sk == MCMCHIP_SCALE_CONSTANT ? 1 : (sk == MCMCHIP_SCALE_DIAGONAL ? p : p * p);
+    const bool slist = (q.scale_kind & MCMCHIP_SCALE_LIST) != 0;
+    const bool inj = q.rng_mode == MCMCHIP_RNG_INJECTED;
+
+    long it = 0;
+    for (int kb = 0; kb < q.nbatch; kb++) {
+        for (int i = lane; i < nout; i += 64) buf[i] = 0.0;
+        for (int i = lane; i < k; i += 64) ibuf[i] = 0.0;
+        for (int jb = 0; jb < q.blen; jb++) {
+            for (int is = 0; is < q.nspac; is++, it++) {
+                const unsigned long long git = q.iter_offset + (unsigned long long)it;
+                double u0, u1, u2 = 0.0, u3 = 0.0;   // which, choose1, choose2, hastings
+                const double *up = inj ? q.unif + ((size_t)e * niter + it) * 4 : nullptr;
+                if (inj) { u0 = up[0]; u1 = up[1]; }
+                else philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, git, 0u, u0, u1);
+                const bool within = u0 < 0.5;          // temper.c:537-538
+                bool have23 = false;
+                double lh;
+                int ci, cj = 0;                        // 1-based components
+                double ly = 0.0, sco = 0.0, spr = 0.0;
+                if (within) {
+                    ci = par ? pick1(u1, k) : (int)S[0];
+                    // normals (temper.c:995-996) and proposal (1003-1024)
+                    if (inj) {
+                        for (int j = lane; j < p; j += 64) Z[j] = q.norm[((size_t)e * niter + it) * p + j];
+                    } else {
+                        for (int j2 = lane; 2 * j2 < p; j2 += 64) {
+                            double za, zb;
+                            philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, git, (uint32_t)(2 + j2), za, zb);
+                            Z[2 * j2] = za;
+                            if (2 * j2 + 1 < p) Z[2 * j2 + 1] = zb;
+                        }
+                    }
+                    __syncthreads();
+                    const double *sc = q.scale + (slist ? (size_t)(ci - 1) * slen1 : 0);
+                    for (int j = lane; j < p; j += 64) {
+                        const double xj = par ? S[(ci - 1) + k * j] : S[1 + j];
+                        double yj;
+                        if (sk == MCMCHIP_SCALE_CONSTANT) yj = __dadd_rn(xj, __dmul_rn(sc[0], Z[j]));
+                        else if (sk == MCMCHIP_SCALE_DIAGONAL) yj = __dadd_rn(xj, __dmul_rn(sc[j], Z[j]));
+                        else {
+                            yj = xj;
+                            for (int i = 0; i < p; i++) yj = __dadd_rn(yj, __dmul_rn(sc[j + p * i], Z[i]));
+                        }
+                        Y[j] = yj;
+                    }
+                    __syncthreads();
+                    ly = lud_temper(q.kind, p, q.par, ci, Y);
+                    lh = ly - L[ci - 1];
+                    if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
+                } else if (par) {
+                    if (inj) u2 = up[2];
+                    else { philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, git, 1u, u2, u3); have23 = true; }
+                    ci = pick1(u1, k);
+                    cj = nb[(ci - 1) * maxnn + pick1(u2, nn[ci - 1]) - 1] + 1;
+                    double xi[TEMPER_MAXP], xj[TEMPER_MAXP];
+                    for (int j = 0; j < p; j++) { xi[j] = S[(ci - 1) + k * j]; xj[j] = S[(cj - 1) + k * j]; }
+                    sco = lud_temper(q.kind, p, q.par, cj, xi);   // (j, x_i) first (temper.c:738-739)
+                    spr = lud_temper(q.kind, p, q.par, ci, xj);   // (i, x_j)
+                    lh = spr + sco - L[cj - 1] - L[ci - 1];       // temper.c:742-744
+                    if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (lane == 0) atomicOr(q.flag, FLAG_NAN); }
+                } else {
+                    ci = (int)S[0];
+                    cj = nb[(ci - 1) * maxnn + pick1(u1, nn[ci - 1]) - 1] + 1;
+                    ly = lud_temper(q.kind, p, q.par, cj, S + 1);
+                    lh = ly - L[ci - 1] + log((double)nn[ci - 1]) - log((double)nn[cj - 1]);   // temper.c:810-812
+                    if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
+                }
+                if (isnan(lh) || (isinf(lh) && lh > 0)) { if (lane == 0) atomicOr(q.flag, FLAG_HASTINGS); lh = -INFINITY; }
+                bool accept = true;
+                if (lh < 0.0) {                                   // temper.c:582-587
+                    if (inj) u3 = up[3];
+                    else if (!have23) philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, git, 1u, u2, u3);
+                    accept = u3 < exp(lh);
+                }
+                __syncthreads();   // every lane has read S / L / Y for this decision
+                if (within) {
+                    if (accept) {
+                        for (int j = lane; j < p; j += 64) {
+                            if (par) S[(ci - 1) + k * j] = Y[j];
+                            else S[1 + j] = Y[j];
+                        }
+                        if (lane == 0) { L[ci - 1] = ly; axn[ci - 1]++; }
+                    }
+                    if (lane == 0) axd[ci - 1]++;
+                } else if (par) {
+                    if (accept) {
+                        for (int j = lane; j < p; j += 64) {      // LDS row swap
+                            const double a = S[(ci - 1) + k * j], b = S[(cj - 1) + k * j];
+                            S[(ci - 1) + k * j] = b;
+                            S[(cj - 1) + k * j] = a;
+                        }
+                        if (lane == 0) { L[ci - 1] = spr; L[cj - 1] = sco; }
+                    }
+                    if (lane == 0) {
+                        int slot = 0;
+                        while (nb[(ci - 1) * maxnn + slot] != cj - 1) slot++;
+                        if (accept) ain[(ci - 1) * maxnn + slot]++;
+                        aid[(ci - 1) * maxnn + slot]++;
+                    }
+                } else {
+                    if (lane == 0) {
+                        int slot = 0;
+                        while (nb[(ci - 1) * maxnn + slot] != cj - 1) slot++;
+                        if (accept) { S[0] = cj; L[cj - 1] = ly; ain[(ci - 1) * maxnn + slot]++; }
+                        aid[(ci - 1) * maxnn + slot]++;
+                    }
+                }
+                __syncthreads();
+            }
+            // batch accumulation once per blen step (temper.c:851-867)
+            for (int i = lane; i < nout; i += 64) buf[i] += par ? S[i] : S[i + 1];
+            if (!par && lane == 0) ibuf[(int)S[0] - 1] += 1.0;
+        }
+        __syncthreads();
+        for (int i = lane; i < nout; i += 64)
+            q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * i] = buf[i] / q.blen;   // temper.c:871-879
+        if (!par)
+            for (int i = lane; i < k; i += 64)
+                q.ibatch[(size_t)e * q.nbatch * k + kb + (size_t)q.nbatch * i] = ibuf[i] / q.blen; // temper.c:881-886
+        __syncthreads();
+    }
+    for (int i = lane; i < k; i += 64) q.acceptx[(size_t)e * k + i] = (double)axn[i] / (double)axd[i];  // 0/0 = NaN (temper.c:889-890)
+    for (int idx = lane; idx < k * k; idx += 64) {
+        const int i = idx % k, j = idx / k;
+        double v = NAN;                                              // NA for non-neighbours (temper.c:896-897)
+        if (q.neighbors[i + k * j]) {
+            int slot = 0;
+            while (nb[i * maxnn + slot] != j) slot++;
+            v = (double)ain[i * maxnn + slot] / (double)aid[i * maxnn + slot];
+        }
+        q.accepti[(size_t)e * k * k + i + k * j] = v;
+    }
+    for (int i = lane; i < nstate; i += 64) q.final_[(size_t)e * nstate + i] = S[i];
+}
+
+int launch_temper(const TemperDev &q, hipStream_t s)
+{
+    if (q.p > TEMPER_MAXP) return set_error(MCMCHIP_EINVAL, "tempering path supports state dimension <= %d", TEMPER_MAXP);
+    if (q.k > 4096) return set_error(MCMCHIP_EINVAL, "too many components");
+    // the neighbour table is needed on the host only for its maximum degree: it is a host array
+    // in the C-ABI, but here we only hold the device copy; bound the degree by k
+    const int k = q.k, p = q.p;
+    int maxnn = k - 1 > 0 ? k - 1 : 1;
+    if (maxnn > 8) {
+        // copy back the 0/1 matrix to find the true maximum degree (small: k*k ints)
+        std::vector<int> h((size_t)k * k);
+        HIP_TRY(hipMemcpyAsync(h.data(), q.neighbors, (size_t)k * k * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        int m = 1;
+        for (int i = 0; i < k; i++) {
+            int c = 0;
+            for (int j = 0; j < k; j++) c += h[i + k * j] != 0;
+            if (c > m) m = c;
+        }
+        maxnn = m;
+    }
+    const int nstate = q.parallel ? k * p : p + 1;
+    const int nout = q.parallel ? k * p : p;
+    TemperLds lay;
+    int o = 0;
+    lay.state = o; o += nstate;
+    lay.L = o; o += k;
+    lay.Y = o; o += p;
+    lay.Z = o; o += p;
+    lay.buf = o; o += nout;
+    lay.ibuf = o; o += k;
+    lay.axn = o; o += (k + 1) / 2;
+    lay.axd = o; o += (k + 1) / 2;
+    lay.ain = o; o += (k * maxnn + 1) / 2;
+    lay.aid = o; o += (k * maxnn + 1) / 2;
+    lay.nn = o; o += (k + 1) / 2;
+    lay.nb = o; o += (k * maxnn + 1) / 2;
+    lay.end = o;
+    size_t bytes = (size_t)o * 8;
+    if (bytes > 64 * 1024) return set_error(MCMCHIP_EINVAL, "tempering state (%zu bytes) does not fit the LDS budget", bytes);
+    hipLaunchKernelGGL(temper_kernel, dim3((unsigned)q.nens), dim3(64), bytes, s, q, lay, maxnn);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}

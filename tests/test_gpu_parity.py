@@ -1,0 +1,433 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI (mcmc_amd.api -> libmcmchip.so),
+against the CPU oracle on the same seeded inputs, and against the committed golden vectors.
+
+Bars (BASELINE.json north_star): accept decisions identical under injected streams, states
+bitwise, log densities and batch means <= 1e-12 relative; initseq/olbm <= 1e-10 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mcmc_amd import abi
+from rhelpers import GOLDEN, glm_binomial, load_logit
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def api():
+    from mcmc_amd import api as a
+    a.init(0)
+    return a
+
+
+@pytest.fixture(scope="module")
+def logit():
+    X, y = load_logit()
+    return X, y, glm_binomial(X, y)
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+def test_native_library_is_loaded(api):
+    import ctypes
+    L = api.load_library()
+    assert isinstance(L, ctypes.CDLL) and b"gfx950" in L.mcmchip_version()
+    with open("/proc/self/maps") as f:
+        assert "libmcmchip.so" in f.read()
+
+
+# ----------------------------------------------------------------------------- metrop, stream path
+def test_metrop_golden_vectors(api, logit):
+    X, y, _ = logit
+    g = np.load(os.path.join(GOLDEN, "metrop_logit.npz"))
+    tg = api.logistic_target(X, y)
+    o = api.metrop(tg, g["init"], int(g["nbatch"]), int(g["blen"]), int(g["nspac"]), scale=float(g["scale"]),
+                   z=g["z"], u=g["u"], debug=True)
+    assert np.array_equal(o["debug.accept"], g["debug_accept"] != 0)
+    assert np.array_equal(o["final"], g["final"])
+    assert np.array_equal(o["accept"], g["accept"]) and np.array_equal(o["accept.batch"], g["accept_batch"])
+    assert rel(o["batch"], g["batch"]) < RTOL
+    assert np.array_equal(np.isnan(o["u"]), np.isnan(g["u_trace"]))
+    fin = np.isfinite(g["log_green"])
+    assert np.max(np.abs(o["log.green"][fin] - g["log_green"][fin])) < 1e-11
+
+
+def test_metrop_c2_4096_chains_injected(api, oracle_mod, logit):
+    # BASELINE config 2: logit posterior, 4096 chains, injected streams, niter = 1000
+    X, y, mle = logit
+    C, nbatch, blen, nspac, d = 4096, 100, 5, 2, 5
+    niter = nbatch * blen * nspac
+    init = mle + 0.05 * np.random.default_rng(42).standard_normal((C, d))
+    rng = np.random.default_rng(7)
+    z = rng.standard_normal((C, niter, d))
+    u = rng.random((C, niter))
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), init, nbatch, blen,
+                            nspac, scale=0.4, z=z, u=u, nthreads=16)
+    o = api.metrop(api.logistic_target(X, y), init, nbatch, blen, nspac, scale=0.4, z=z, u=u)
+    assert o["path"] == "stream"
+    # identical accept decisions <=> identical accept counts per batch and bitwise equal states
+    assert np.array_equal(o["accept.batch"], ref["accept_batch"])
+    assert np.array_equal(o["accept"], ref["accept"])
+    assert np.array_equal(o["final"], ref["final"])
+    assert rel(o["batch"], ref["batch"]) < RTOL
+    assert 0.15 < o["accept"].mean() < 0.35
+
+
+@pytest.mark.parametrize("scale_kind", ["scalar", "vector", "matrix"])
+@pytest.mark.parametrize("outfun", [None, [2, 3], [-2], [True, False, True, False, True], "moments2"])
+def test_metrop_trace_scale_and_outfun(api, oracle_mod, logit, scale_kind, outfun):
+    # tests/logitvec.R, logitmat.R, logitidx.R, logitnegidx.R, logitlogidx.R, logitfun.R analogues
+    X, y, mle = logit
+    d, C, nbatch, blen, nspac = 5, 16, 10, 5, 3
+    niter = nbatch * blen * nspac
+    rng = np.random.default_rng(3)
+    init = mle + 0.1 * rng.standard_normal((C, d))
+    z, u = rng.standard_normal((C, niter, d)), rng.random((C, niter))
+    scale = {"scalar": 0.4, "vector": np.array([0.5, 0.4, 0.3, 0.35, 0.45]),
+             "matrix": 0.9 * np.linalg.cholesky(np.linalg.inv(X.T @ X / 4 + np.eye(d) / 4))}[scale_kind]
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), init, nbatch, blen,
+                            nspac, scale=scale, z=z, u=u, outfun=outfun, debug=True)
+    o = api.metrop(api.logistic_target(X, y), init, nbatch, blen, nspac, scale=scale, z=z, u=u, outfun=outfun,
+                   debug=True)
+    assert np.array_equal(o["debug.accept"], ref["debug_accept"] != 0)
+    assert np.array_equal(o["current"], ref["current"]) and np.array_equal(o["proposal"], ref["proposal"])
+    assert np.array_equal(o["z"], ref["z"])
+    assert np.array_equal(np.isnan(o["u"]), np.isnan(ref["u"]))
+    assert np.array_equal(o["u"][~np.isnan(o["u"])], ref["u"][~np.isnan(ref["u"])])
+    assert o["batch"].shape == ref["batch"].shape and rel(o["batch"], ref["batch"]) < RTOL
+    assert np.array_equal(o["final"], ref["final"])
+    # reference identities: batch == path when blen = nspac = 1 is covered below; accept bookkeeping here
+    assert np.allclose(o["accept"], o["accept.batch"].mean(axis=1))
+
+
+@pytest.mark.parametrize("kind", ["simplex", "ball", "mvnorm", "normmix", "naive"])
+def test_metrop_other_targets(api, oracle_mod, logit, kind):
+    rng = np.random.default_rng(5)
+    d = 5
+    kw, init, scale = {}, np.zeros((32, d)), 0.1
+    if kind == "simplex":
+        K, kw = abi.T_SIMPLEX, dict(par=[1.0])           # tests/accept-batch.R
+    elif kind == "ball":
+        K, scale = abi.T_BALL, 0.4                        # tests/circle.R: -Inf proposals draw no uniform
+    elif kind == "mvnorm":
+        A = rng.standard_normal((d, d))
+        P = A @ A.T + d * np.eye(d)
+        K, kw, scale = abi.T_MVNORM, dict(par=np.concatenate([rng.standard_normal(d), P.ravel()])), 0.5
+        init = rng.standard_normal((32, d))
+    elif kind == "normmix":
+        par = abi.normmix_par([0.5, 0.3, 0.2], rng.standard_normal((3, d)) * 2, [1.0, 0.5, 2.0])
+        K, kw, scale = abi.T_NORMMIX, dict(par=par), 1.0
+        init = rng.standard_normal((32, d))
+    else:
+        X, y, mle = logit
+        K, kw, scale = abi.T_LOGISTIC_NAIVE, dict(x=X, y=y, prior_c=0.0), 0.3   # tests/logit.R:40-48
+        init = mle + 0.05 * rng.standard_normal((32, d))
+    nbatch, blen, nspac = 30, 4, 2
+    niter = nbatch * blen * nspac
+    z, u = rng.standard_normal((32, niter, d)), rng.random((32, niter))
+    ref = oracle_mod.metrop(oracle_mod.Target(K, d, **kw), init, nbatch, blen, nspac, scale=scale, z=z, u=u, debug=True)
+    o = api.metrop(api.Target(K, d, **kw), init, nbatch, blen, nspac, scale=scale, z=z, u=u, debug=True)
+    assert np.array_equal(o["debug.accept"], ref["debug_accept"] != 0)
+    assert np.array_equal(np.isnan(o["u"]), np.isnan(ref["u"]))
+    assert np.array_equal(o["final"], ref["final"])
+    assert rel(o["batch"] + 1.0, ref["batch"] + 1.0) < RTOL
+    lg_o, lg_r = o["log.green"], ref["log_green"]
+    assert np.array_equal(np.isneginf(lg_o), np.isneginf(lg_r))
+    f = np.isfinite(lg_r)
+    assert np.max(np.abs(lg_o[f] - lg_r[f])) < 1e-11
+
+
+def test_metrop_single_chain_shapes_and_identities(api, logit):
+    # tests/logit.R:67-69,102: with blen = nspac = 1 batch is the path; result shapes as in R
+    X, y, mle = logit
+    o = api.metrop(api.logistic_target(X, y), mle, 200, scale=0.4, seed=99, debug=True)
+    assert o["batch"].shape == (200, 5) and o["current"].shape == (200, 5) and np.ndim(o["accept"]) == 0
+    assert np.all(o["batch"][:-1] == o["current"][1:]) and np.all(o["current"][0] == o["initial"])
+    assert np.all(o["batch"][-1] == o["final"])
+    path = np.where(o["debug.accept"][:, None], o["proposal"], o["current"])
+    assert np.all(path == o["batch"])
+    assert np.max(np.abs(o["proposal"] - (o["current"] + 0.4 * o["z"]))) < 1e-15
+    assert list(o.keys())[:11] == ["accept", "batch", "initial", "final", "accept.batch", "current", "proposal",
+                                   "log.green", "u", "z", "debug.accept"]     # metrop.c:124-128,174-179
+
+
+def test_metrop_philox_trajectory_replayed_by_oracle(api, oracle_mod, logit):
+    # device RNG: the z/u the device drew, fed to the oracle as injected streams, give the same chain;
+    # and the device's Philox/Box-Muller agrees with the oracle's restatement of it
+    X, y, mle = logit
+    C, nbatch, blen, nspac = 64, 25, 2, 2
+    init = mle + 0.05 * np.random.default_rng(1).standard_normal((C, 5))
+    o = api.metrop(api.logistic_target(X, y), init, nbatch, blen, nspac, scale=0.4, seed=2024, debug=True,
+                   chain_offset=1000)
+    u_fill = np.where(np.isnan(o["u"]), 0.5, o["u"])
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, 5, x=X, y=y, prior_c=0.125), init, nbatch, blen, nspac,
+                            scale=0.4, z=o["z"], u=u_fill, debug=True)
+    assert np.array_equal(o["debug.accept"], ref["debug_accept"] != 0)
+    assert np.array_equal(o["final"], ref["final"])
+    ref2 = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, 5, x=X, y=y, prior_c=0.125), init, nbatch, blen, nspac,
+                             scale=0.4, seed=2024, chain_offset=1000, debug=True)
+    assert np.max(np.abs(o["z"] - ref2["z"])) < 1e-12
+    assert np.array_equal(o["debug.accept"], ref2["debug_accept"] != 0)
+    zz = o["z"].ravel()
+    assert abs(zz.mean()) < 0.02 and abs(zz.std() - 1) < 0.02
+
+
+def test_metrop_restart_equals_long_run(api, logit):
+    # tests/saveseed.R:12-17: rbind(metrop(out)$batch, metrop(metrop(out))$batch) identical to
+    # metrop(out, nbatch = 2 * out$nbatch)$batch
+    X, y, mle = logit
+    tg = api.logistic_target(X, y)
+    init = mle + 0.05 * np.random.default_rng(8).standard_normal((32, 5))
+    out = api.metrop(tg, init, 50, blen=3, scale=0.4, seed=5)
+    a = api.metrop(out)
+    b = api.metrop(a)
+    long = api.metrop(out, nbatch=100)
+    assert np.array_equal(np.concatenate([a["batch"], b["batch"]], axis=1), long["batch"])
+    assert np.array_equal(b["final"], long["final"])
+    # sharding independence: chains 16.. run as their own call with chain_offset give the same numbers
+    part = api.metrop(tg, init[16:], 50, blen=3, scale=0.4, seed=5, chain_offset=16)
+    assert np.array_equal(part["batch"], out["batch"][16:])
+
+
+def test_metrop_errors(api, logit):
+    X, y, mle = logit
+    with pytest.raises(api.McmcHipError, match="log unnormalized density -Inf at initial state"):
+        api.metrop(api.Target(abi.T_SIMPLEX, 3, par=[0.0]), np.array([0.5, 0.6, 0.1]), 10, seed=1)
+    tg = api.logistic_target(X, y)
+    with pytest.raises(api.McmcHipError, match='argument "nbatch" must be positive'):
+        api.metrop(tg, mle, 0, seed=1)
+    with pytest.raises(api.McmcHipError, match='all elements of "state" must be finite'):
+        api.metrop(tg, np.array([0, 0, np.inf, 0, 0.0]), 5, seed=1)
+    with pytest.raises(ValueError, match='length of "scale" vector not d or 1'):
+        api.metrop(tg, mle, 5, scale=[1.0, 2.0], seed=1)
+    with pytest.raises(ValueError, match="any\\(outfun == 0\\)"):
+        api.metrop(tg, mle, 5, outfun=[0, 1], seed=1)
+
+
+# ----------------------------------------------------------------------------- metrop, MFMA path
+def _synthetic(n, d, seed=42):
+    rng = np.random.default_rng(seed)
+    X = np.empty((n, d))
+    X[:, 0] = 1.0
+    X[:, 1:] = rng.standard_normal((n, d - 1)) / np.sqrt(d)
+    beta = 0.5 * rng.standard_normal(d)
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    return X, y, beta
+
+
+@pytest.mark.parametrize("n,d,C", [(20000, 64, 256), (5003, 5, 100), (8192, 20, 300), (4099, 33, 64)])
+def test_logdens_mfma_vs_oracle(api, oracle_mod, n, d, C):
+    X, y, beta = _synthetic(n, d, seed=n)
+    states = beta + 0.3 * np.random.default_rng(1).standard_normal((C, d))
+    states[0] *= 40.0           # |eta| large: exercises the tails of the softplus
+    tg = api.logistic_target(X, y)
+    ref = oracle_mod.logdens(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), states)
+    got_m = api.logdens(tg, states, path=abi.PATH_MFMA)
+    got_s = api.logdens(tg, states, path=abi.PATH_STREAM)
+    assert rel(got_m, ref) < RTOL and rel(got_s, ref) < RTOL
+
+
+@pytest.mark.parametrize("scale_kind", ["scalar", "matrix"])
+def test_metrop_mfma_injected_vs_oracle(api, oracle_mod, scale_kind):
+    n, d, C, nbatch, blen, nspac = 8192, 16, 128, 6, 3, 2
+    niter = nbatch * blen * nspac
+    X, y, beta = _synthetic(n, d)
+    rng = np.random.default_rng(2)
+    init = beta + 0.01 * rng.standard_normal((C, d))
+    z, u = rng.standard_normal((C, niter, d)), rng.random((C, niter))
+    scale = 0.02 if scale_kind == "scalar" else 0.02 * np.linalg.cholesky(np.eye(d) + 0.3)
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), init, nbatch, blen, nspac,
+                            scale=scale, z=z, u=u, outfun="moments2", nthreads=16)
+    o = api.metrop(api.logistic_target(X, y), init, nbatch, blen, nspac, scale=scale, z=z, u=u, outfun="moments2",
+                   path=abi.PATH_MFMA)
+    assert o["path"] == "mfma"
+    assert np.array_equal(o["accept.batch"], ref["accept_batch"])
+    assert np.array_equal(o["final"], ref["final"])
+    assert rel(o["batch"], ref["batch"]) < RTOL
+    assert 0.05 < o["accept"].mean() < 0.95
+    s = api.metrop(api.logistic_target(X, y), init, nbatch, blen, nspac, scale=scale, z=z, u=u, outfun="moments2",
+                   path=abi.PATH_STREAM)
+    assert np.array_equal(s["final"], o["final"])
+
+
+def test_metrop_mfma_philox_restart_and_sharding(api):
+    n, d, C = 8192, 64, 256
+    X, y, beta = _synthetic(n, d)
+    tg = api.logistic_target(X, y)
+    init = beta + 1e-3 * np.random.default_rng(3).standard_normal((C, d))
+    out = api.metrop(tg, init, 4, blen=2, scale=0.01, seed=77)
+    assert out["path"] == "mfma"
+    both = api.metrop(out, nbatch=8)
+    a = api.metrop(out)
+    b = api.metrop(a)
+    assert np.array_equal(np.concatenate([a["batch"], b["batch"]], axis=1), both["batch"])
+    part = api.metrop(tg, init[128:], 4, blen=2, scale=0.01, seed=77, chain_offset=128)
+    assert np.array_equal(part["batch"], out["batch"][128:])
+
+
+def test_full_size_c3_logdens_properties(api, oracle_mod):
+    # BASELINE config 3 data shape (n = 1e6, d = 64): MFMA path against the independent stream
+    # kernel on all chains, against the oracle on a few
+    n, d, C = 1_000_000, 64, 256
+    X, y, beta = _synthetic(n, d)
+    tg = api.logistic_target(X, y)
+    states = beta + 1e-3 * np.random.default_rng(4).standard_normal((C, d))
+    m = api.logdens(tg, states, path=abi.PATH_MFMA)
+    s = api.logdens(tg, states, path=abi.PATH_STREAM)
+    assert rel(m, s) < RTOL
+    ref = oracle_mod.logdens(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), states[:4])
+    assert rel(m[:4], ref) < RTOL
+    # permutation invariance of the observations (a checksum-of-checksums style property)
+    perm = np.random.default_rng(5).permutation(n)
+    m2 = api.logdens(api.logistic_target(X[perm], y[perm]), states[:64], path=abi.PATH_MFMA)
+    assert rel(m2, m[:64]) < 1e-11
+
+
+# ----------------------------------------------------------------------------- temper
+def test_temper_golden_vectors(api):
+    g = np.load(os.path.join(GOLDEN, "temper_witch.npz"))
+    tg = api.Target(abi.T_WITCH, 3, par=g["witch"])
+    E = g["unif"].shape[0]
+    args = (int(g["nbatch"]), int(g["blen"]), int(g["nspac"]), float(g["scale"]))
+    o = api.temper(tg, np.zeros((E, 6, 3)), g["neighbors"], *args, parallel=True, unif=g["unif"], norm=g["norm"])
+    assert np.array_equal(o["final"], g["par_final"])
+    assert np.array_equal(o["acceptx"], g["par_acceptx"], equal_nan=True)
+    assert np.array_equal(o["accepti"], g["par_accepti"], equal_nan=True)
+    assert rel(o["batch"] + 1, g["par_batch"] + 1) < RTOL
+    init_s = np.tile(np.array([1.0, 0, 0, 0]), (E, 1))
+    o = api.temper(tg, init_s, g["neighbors"], *args, parallel=False, unif=g["unif"], norm=g["norm"])
+    assert np.array_equal(o["final"], g["ser_final"])
+    assert np.array_equal(o["acceptx"], g["ser_acceptx"], equal_nan=True)
+    assert np.array_equal(o["accepti"], g["ser_accepti"], equal_nan=True)
+    assert np.array_equal(o["ibatch"], g["ser_ibatch"])
+    assert rel(o["batch"] + 1, g["ser_batch"] + 1) < RTOL
+
+
+@pytest.mark.parametrize("parallel", [True, False])
+@pytest.mark.parametrize("target", ["witch", "mixture"])
+@pytest.mark.parametrize("scale_kind", ["scalar", "list_vector", "matrix"])
+def test_temper_vs_oracle(api, oracle_mod, parallel, target, scale_kind):
+    rng = np.random.default_rng(21)
+    k, E, nbatch, blen, nspac = 8, 48, 12, 5, 3
+    niter = nbatch * blen * nspac
+    if target == "witch":
+        p = 3
+        par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+        K = abi.T_WITCH
+        x0 = np.zeros(p)
+    else:
+        p = 2
+        betas = np.geomspace(1.0, 0.05, k)
+        par = np.concatenate([[float(k)], betas, abi.normmix_par([0.5, 0.5], [[-4.0, -4.0], [4.0, 4.0]], 1.0)])
+        K = abi.T_TEMPERED_NORMMIX          # BASELINE config 4 (ii): bimodal normal mixture
+        x0 = np.array([4.0, 4.0])
+    i, j = np.indices((k, k))
+    nb = np.abs(i - j) == 1
+    scale = {"scalar": 0.4, "list_vector": [np.full(p, 0.2 + 0.1 * c) for c in range(k)],
+             "matrix": 0.3 * np.linalg.cholesky(np.eye(p) + 0.5)}[scale_kind]
+    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+    if parallel:
+        init = np.tile(x0, (E, k, 1))
+    else:
+        init = np.column_stack([rng.integers(1, k + 1, E).astype(float), np.tile(x0, (E, 1))])
+    ref = oracle_mod.temper(oracle_mod.Target(K, p, par=par), init, nb, nbatch, blen, nspac, scale, parallel=parallel,
+                            unif=unif, norm=norm)
+    o = api.temper(api.Target(K, p, par=par), init, nb, nbatch, blen, nspac, scale, parallel=parallel,
+                   unif=unif, norm=norm)
+    assert np.array_equal(o["final"], ref["final"])
+    assert np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True)
+    assert np.array_equal(o["accepti"], ref["accepti"], equal_nan=True)
+    assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
+    if not parallel:
+        assert np.array_equal(o["ibatch"], ref["ibatch"])
+    assert np.array_equal(np.isnan(o["accepti"][0]), ~nb)      # NA exactly for non-neighbours
+
+
+def test_temper_philox_matches_oracle_restatement(api, oracle_mod):
+    k, p, E = 6, 3, 32
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    i, j = np.indices((k, k))
+    nb = (np.abs(i - j) == 1) | (np.abs(i - j) == 2)
+    o = api.temper(api.Target(abi.T_WITCH, p, par=par), np.zeros((E, k, p)), nb, 20, 13, 7, 0.3456789, parallel=True,
+                   seed=11, ens_offset=5)
+    ref = oracle_mod.temper(oracle_mod.Target(abi.T_WITCH, p, par=par), np.zeros((E, k, p)), nb, 20, 13, 7, 0.3456789,
+                            parallel=True, seed=11, ens_offset=5)
+    # same counter-based draws on both sides; Box-Muller differs by ulps, decisions almost surely equal
+    assert np.allclose(o["acceptx"], ref["acceptx"], atol=0.02)
+    assert np.mean(np.abs(o["final"] - ref["final"]) < 1e-9) > 0.9
+    a = api.temper(o)
+    both = api.temper(o, nbatch=40)
+    assert np.array_equal(both["batch"][:, :20], a["batch"])    # restart continues the stream
+
+
+# ----------------------------------------------------------------------------- initseq / olbm
+def test_diag_golden_vectors(api):
+    g = np.load(os.path.join(GOLDEN, "diag.npz"))
+    x = g["x"].astype(np.float64)
+    res = api.initseq(x)
+    for c in range(3):
+        for key in ("gamma0", "Gamma.pos", "Gamma.dec", "Gamma.con", "var.pos", "var.dec", "var.con"):
+            want = g["c%d_%s" % (c, key.replace(".", "_"))]
+            got = np.asarray(res[c][key])
+            assert got.shape == want.shape, key
+            assert np.max(np.abs(got - want)) <= 1e-10 * np.max(np.abs(want)) + 1e-300, key
+    var = api.olbm(x, int(g["olbm_len"]))
+    assert rel(var, g["olbm_var"]) < 1e-10
+
+
+def test_initseq_ar1_identities_and_oracle(api, oracle_mod):
+    # tests/initseq.R:6-48 at its size (n = 1e5, rho = 0.99)
+    rng = np.random.default_rng(42)
+    n, rho = 100000, 0.99
+    e = rng.standard_normal(n)
+    x = np.empty(n)
+    x[0] = e[0] / np.sqrt(1 - rho * rho)
+    for t in range(1, n):
+        x[t] = rho * x[t - 1] + e[t]
+    out = api.initseq(x)
+    ref = oracle_mod.initseq(x - x.mean())
+    assert len(out["Gamma.pos"]) == len(ref["Gamma.pos"])
+    for key in ("gamma0", "Gamma.pos", "Gamma.dec", "Gamma.con", "var.pos", "var.dec", "var.con"):
+        assert np.max(np.abs(np.asarray(out[key]) - np.asarray(ref[key]))) <= 1e-10 * np.max(np.abs(ref[key])), key
+    assert np.array_equal(out["Gamma.dec"], np.minimum.accumulate(out["Gamma.pos"]))
+    assert out["Gamma.pos"][-1] == 0 and out["Gamma.dec"][-1] == 0 and abs(out["Gamma.con"][-1]) < 1e-8
+    assert np.min(np.diff(np.diff(out["Gamma.con"]))) > -np.sqrt(np.finfo(float).eps)
+    for s in ("pos", "dec", "con"):
+        assert np.isclose(2 * out["Gamma." + s].sum() - out["gamma0"], out["var." + s], rtol=1e-12)
+
+
+def test_initseq_edge_cases(api, oracle_mod):
+    rng = np.random.default_rng(1)
+    for n in (2, 3, 17, 64, 2049, 4099):
+        x = rng.standard_normal(n)
+        out, ref = api.initseq(x), oracle_mod.initseq(x - x.mean())
+        assert len(out["Gamma.pos"]) == len(ref["Gamma.pos"]), n
+        assert np.allclose(out["Gamma.con"], ref["Gamma.con"], rtol=1e-10, atol=1e-13)
+        assert np.isclose(out["var.con"], ref["var.con"], rtol=1e-10, atol=1e-13)
+    # never-negative case: a linear trend keeps Gamma positive up to len/2 pairs
+    x = np.arange(40.0)
+    out, ref = api.initseq(x), oracle_mod.initseq(x - x.mean())
+    assert len(out["Gamma.pos"]) == len(ref["Gamma.pos"])
+    with pytest.raises(ValueError):
+        api.initseq(np.array([1.0, np.nan, 2.0]))
+
+
+@pytest.mark.parametrize("n,p,blen", [(20000, 3, 25), (5000, 40, 500), (1000, 1, 1), (300, 17, 300), (70000, 16, 1000)])
+def test_olbm_vs_oracle(api, oracle_mod, n, p, blen):
+    rng = np.random.default_rng(n + p)
+    e = rng.standard_normal((n, p)) + 3.0
+    x = np.cumsum(e * 0.1, axis=0) * 0.01 + e     # mildly autocorrelated, non-zero mean
+    ref, refmean = oracle_mod.olbm(x, blen)
+    got = api.olbm(x, blen)
+    assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))
+    assert np.array_equal(got, got.T)
+    got2 = api.olbm(x, blen, demean=False)        # R/olbm.R quirk: still demeans
+    assert np.max(np.abs(got2 - ref)) <= 1e-10 * np.max(np.abs(ref))
+    with pytest.raises(ValueError, match="batch.length must be <= nrow"):
+        api.olbm(x, n + 1)

@@ -1,0 +1,180 @@
+"""CPU-only tests (-m "not gpu"): the C-ABI library loads and exports every symbol of
+include/mcmchip.h, ctypes struct layouts match the header, the host logic mirrors the
+reference's argument rules, the product fails loudly without a GPU, and the N>1 sharding
+path works under gloo with world_size 2."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from mcmc_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mcmchip.h")
+
+
+def test_library_exports_every_declared_symbol():
+    from mcmc_amd import api
+    L = api.load_library()
+    declared = re.findall(r"\b(mcmchip_[a-z_]+)\s*\(", open(HEADER).read())
+    declared = sorted(set(d for d in declared if not d.endswith("_desc")))
+    assert sorted(abi.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.mcmchip_version()
+
+
+def test_struct_layouts_match_header():
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "mcmchip.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu\n", sizeof(mcmchip_target_desc), sizeof(mcmchip_metrop_args),
+             sizeof(mcmchip_metrop_out), sizeof(mcmchip_temper_args), sizeof(mcmchip_temper_out));
+      printf("%zu %zu %zu %zu\n", offsetof(mcmchip_metrop_args, seed), offsetof(mcmchip_metrop_args, path),
+             offsetof(mcmchip_metrop_out, nout), offsetof(mcmchip_temper_args, seed));
+      return 0; }'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [ctypes.sizeof(s) for s in (abi.TargetDesc, abi.MetropArgs, abi.MetropOut, abi.TemperArgs, abi.TemperOut)]
+    offs = [abi.MetropArgs.seed.offset, abi.MetropArgs.path.offset, abi.MetropOut.nout.offset, abi.TemperArgs.seed.offset]
+    assert [int(v) for v in out] == sizes + offs
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mcmc_amd import api
+    with pytest.raises(api.McmcHipError):
+        api.Target(abi.T_BALL, 3)
+    with pytest.raises(api.McmcHipError):
+        api.olbm(np.zeros((10, 2)), 2)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mcmc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "oracle.h" not in text and "liboracle" not in text, f
+
+
+def test_scale_and_outfun_rules():
+    # metrop.c:333-365
+    assert abi.classify_scale(0.4, 5)[0] == abi.SCALE_CONSTANT
+    assert abi.classify_scale(np.ones(5), 5)[0] == abi.SCALE_DIAGONAL
+    k, flat = abi.classify_scale(np.arange(9.0).reshape(3, 3), 3)
+    assert k == abi.SCALE_FULL and list(flat[:3]) == [0.0, 3.0, 6.0]       # column-major like R
+    with pytest.raises(ValueError, match="not d by d"):
+        abi.classify_scale(np.eye(4), 3)
+    with pytest.raises(ValueError, match="not d or 1"):
+        abi.classify_scale([1.0, 2.0], 3)
+    # metrop.c:416-503
+    assert abi.resolve_outfun(None, 4)[2] == 4
+    assert list(abi.resolve_outfun([2, 3], 4)[1]) == [0, 1, 1, 0]
+    assert list(abi.resolve_outfun([-2], 4)[1]) == [1, 0, 1, 1]
+    assert list(abi.resolve_outfun([True, False, True, False], 4)[1]) == [1, 0, 1, 0]
+    for bad, msg in [([0, 1], "outfun == 0"), ([1.5], "as.integer"), ([7], "abs\\(outfun\\)"),
+                     ([1, -2], "outfun > 0\\) & any\\(outfun < 0"), ([np.nan], "NA or NaN"),
+                     ([True, False], "length\\(outfun\\) != length\\(initial\\)")]:
+        with pytest.raises(ValueError, match=msg):
+            abi.resolve_outfun(bad, 4)
+    # temper.c:78-87: list scale
+    k, flat = abi.classify_scale([0.1, 0.2, 0.3], 2, ncomp=3)
+    assert k == (abi.SCALE_CONSTANT | abi.SCALE_LIST) and flat.size == 3
+
+
+def test_oracle_error_behaviour(oracle_mod):
+    # metrop.c:60-65,196-197; temper.c:36-41
+    tg = oracle_mod.Target(abi.T_SIMPLEX, 3, par=[0.0])
+    with pytest.raises(oracle_mod.OracleError, match="-Inf at initial state"):
+        oracle_mod.metrop(tg, np.array([0.5, 0.6, 0.1]), 10, seed=1)
+    with pytest.raises(oracle_mod.OracleError, match='"nbatch" must be positive'):
+        oracle_mod.metrop(tg, np.array([0.1, 0.1, 0.1]), 0, seed=1)
+    w = oracle_mod.Target(abi.T_WITCH, 2, par=[0.2, 0.5, 0.7])
+    nb = np.array([[0, 1, 0], [0, 0, 1], [0, 1, 0]], dtype=bool)
+    with pytest.raises(oracle_mod.OracleError, match="symmetric"):
+        oracle_mod.temper(w, np.zeros((3, 2)), nb, 5, seed=1, parallel=True)
+
+
+def test_oracle_philox_sharding_and_restart(oracle_mod):
+    # the Philox addressing the device uses: independent of sharding, restartable (tests/saveseed.R)
+    tg = oracle_mod.Target(abi.T_BALL, 4)
+    init = np.zeros((6, 4))
+    whole = oracle_mod.metrop(tg, init, 20, 2, scale=0.3, seed=9)
+    part = oracle_mod.metrop(tg, init[4:], 20, 2, scale=0.3, seed=9, chain_offset=4)
+    assert np.array_equal(whole["batch"][4:], part["batch"])
+    a = oracle_mod.metrop(tg, init, 10, 2, scale=0.3, seed=9)
+    b = oracle_mod.metrop(tg, a["final"], 10, 2, scale=0.3, seed=9, iter_offset=a["iter_offset"])
+    assert np.array_equal(np.concatenate([a["batch"], b["batch"]], axis=1), whole["batch"])
+
+
+def test_softplus_arithmetic_accuracy():
+    # the MFMA path's table-driven log1p(exp(-a)) (mcmc_amd/csrc/softplus.h), compiled for the host
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_softplus
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(0, 40, 200000), rng.uniform(0, 700, 20000), [0.0, 1e-300, 700.0, 745.0, 1e4]])
+    out, ref = check_softplus.run(a)
+    ok = a <= 700
+    assert np.max(np.abs(out[ok] - ref[ok]) / ref[ok]) < 4.5 * 2.0 ** -53
+    assert np.all(out[~ok] < 1e-300)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+import oracle
+from mcmc_amd import abi, dist as mdist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+tg = oracle.Target(abi.T_BALL, 4)
+init = np.zeros((7, 4))                       # ragged: 4 + 3 chains
+def run_local(block, lo):
+    r = oracle.metrop(tg, block, 12, 3, scale=0.3, seed=5, chain_offset=lo)
+    return {"batch": r["batch"], "accept": r["accept"], "accept.batch": r["accept_batch"]}
+out = mdist.metrop_sharded(run_local, init)
+whole = oracle.metrop(tg, init, 12, 3, scale=0.3, seed=5)
+assert out["shard"] == ((0, 4) if dist.get_rank() == 0 else (4, 7))
+assert np.array_equal(out["batch.all"], whole["batch"])
+assert np.array_equal(out["accept.all"], whole["accept"])
+assert np.array_equal(out["accept.batch.all"], whole["accept_batch"])
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_sharded_metrop_world_size_2_gloo(oracle_mod):
+    # N>1 path: shard chains over ranks, Philox keyed by global chain id, one all-gather at the end.
+    # (the oracle stands in for the device sampler here: what is under test is the sharding)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    with tempfile.TemporaryDirectory() as td:
+        w = os.path.join(td, "worker.py")
+        open(w, "w").write(_WORKER)
+        procs = [subprocess.Popen([sys.executable, w, ROOT, port, str(r)], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in o, o
+
+
+def test_shard_range():
+    from mcmc_amd.dist import shard_range
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [shard_range(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
