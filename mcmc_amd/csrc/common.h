@@ -100,6 +100,20 @@ struct OutBuf {
     template <class T> T *as() { return (T *)ptr; }
 };
 
+// Separately rounded multiply / add.  HIP's __dmul_rn/__dadd_rn are plain `*`/`+` and get
+// contracted into v_fma_f64 under hipcc's default -ffp-contract=fast-honor-pragmas; the reference
+// is built without FMA contraction (x86-64 R), and bitwise-equal proposals need the two roundings.
+__device__ __forceinline__ double mul_nofma(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double add_nofma(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 // error flag bits written by kernels
 #define FLAG_NEGINF_INIT 1  // log unnormalized density -Inf at initial state (metrop.c:196-197)
 #define FLAG_POSINF 2       // logh: func returned +Inf (metrop.c:317-318)

@@ -217,14 +217,14 @@ __device__ __forceinline__ void make_proposal(const UpdParams &q, long c, long l
     if (q.scale_kind == MCMCHIP_SCALE_CONSTANT) {
         const double s0 = q.scale[0];
         for (int j = 0; j < d; j++)
-            q.prop[(size_t)j * ldc + c] = __dadd_rn(q.state[(size_t)j * ldc + c], __dmul_rn(s0, zl[j]));
+            q.prop[(size_t)j * ldc + c] = add_nofma(q.state[(size_t)j * ldc + c], mul_nofma(s0, zl[j]));
     } else if (q.scale_kind == MCMCHIP_SCALE_DIAGONAL) {
         for (int j = 0; j < d; j++)
-            q.prop[(size_t)j * ldc + c] = __dadd_rn(q.state[(size_t)j * ldc + c], __dmul_rn(q.scale[j], zl[j]));
+            q.prop[(size_t)j * ldc + c] = add_nofma(q.state[(size_t)j * ldc + c], mul_nofma(q.scale[j], zl[j]));
     } else {
         for (int j = 0; j < d; j++) {
             double a = q.state[(size_t)j * ldc + c];
-            for (int i = 0; i < d; i++) a = __dadd_rn(a, __dmul_rn(q.scale[j + (size_t)d * i], zl[i]));
+            for (int i = 0; i < d; i++) a = add_nofma(a, mul_nofma(q.scale[j + (size_t)d * i], zl[i]));
             q.prop[(size_t)j * ldc + c] = a;
         }
     }
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     if (is == q.nspac - 1) {                   // metrop.c:273-275
         for (int k = 0; k < q.nout; k++) {
             double v = q.state[(size_t)q.out_map[k] * ldc + c];
-            if (k >= q.sq_from) v = __dmul_rn(v, v);
-            q.buf[(size_t)k * ldc + c] = __dadd_rn(q.buf[(size_t)k * ldc + c], v);
+            if (k >= q.sq_from) v = mul_nofma(v, v);
+            q.buf[(size_t)k * ldc + c] = add_nofma(q.buf[(size_t)k * ldc + c], v);
         }
         if (jb == q.blen - 1) {                // metrop.c:279-283
             for (int k = 0; k < q.nout; k++) {

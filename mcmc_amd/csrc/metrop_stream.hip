@@ -15,7 +15,7 @@
 // (2n exp/log1p per chain-iteration), not HBM.
 //
 // Arithmetic fidelity: the proposal is x + s*z with separately rounded multiply and add
-// (__dmul_rn/__dadd_rn: no FMA contraction, as in the reference's x86-64 build); full-matrix
+// (mul_nofma/add_nofma: no FMA contraction, as in the reference's x86-64 build); full-matrix
 // scale accumulates column by column in i order (metrop.c:391-399).
 #include "kernels.h"
 #include "philox.h"
@@ -89,13 +89,13 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
                 // ---- proposal (metrop.c:380-403)
                 if (p.scale_kind == MCMCHIP_SCALE_CONSTANT) {
                     const double s0 = p.scale[0];
-                    for (int j = g; j < d; j += G) Y[j] = __dadd_rn(X[j], __dmul_rn(s0, Z[j]));
+                    for (int j = g; j < d; j += G) Y[j] = add_nofma(X[j], mul_nofma(s0, Z[j]));
                 } else if (p.scale_kind == MCMCHIP_SCALE_DIAGONAL) {
-                    for (int j = g; j < d; j += G) Y[j] = __dadd_rn(X[j], __dmul_rn(p.scale[j], Z[j]));
+                    for (int j = g; j < d; j += G) Y[j] = add_nofma(X[j], mul_nofma(p.scale[j], Z[j]));
                 } else {
                     for (int j = g; j < d; j += G) {
                         double a = X[j];
-                        for (int i = 0; i < d; i++) a = __dadd_rn(a, __dmul_rn(p.scale[j + (size_t)d * i], Z[i]));
+                        for (int i = 0; i < d; i++) a = add_nofma(a, mul_nofma(p.scale[j + (size_t)d * i], Z[i]));
                         Y[j] = a;
                     }
                 }
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
             // ---- outfun + batch accumulation, once per blen step (metrop.c:273-275)
             for (int k = g; k < nout; k += G) {
                 double v = X[p.out_map[k]];
-                if (k >= p.sq_from) v = __dmul_rn(v, v);
-                B[k] = __dadd_rn(B[k], v);
+                if (k >= p.sq_from) v = mul_nofma(v, v);
+                B[k] = add_nofma(B[k], v);
             }
         }
         if (live) {

@@ -77,7 +77,7 @@ template <int G> __device__ double lud_group(const TargetView &t, const double *
         for (long i = g; i < t.n; i += G) {
             const double *xi = t.x + (size_t)i * d;
             double eta = 0.0;
-            for (int j = 0; j < d; j++) eta = __dadd_rn(eta, __dmul_rn(xi[j], v[j]));
+            for (int j = 0; j < d; j++) eta = add_nofma(eta, mul_nofma(xi[j], v[j]));
             if (t.y[i] == 1.0) lp += (eta < 0) ? eta - log1p(exp(eta)) : -log1p(exp(-eta));
             else lq += (eta < 0) ? -log1p(exp(eta)) : -eta - log1p(exp(-eta));
         }
@@ -93,7 +93,7 @@ template <int G> __device__ double lud_group(const TargetView &t, const double *
         for (long i = g; i < t.n; i += G) {
             const double *xi = t.x + (size_t)i * d;
             double eta = 0.0;
-            for (int j = 0; j < d; j++) eta = __dadd_rn(eta, __dmul_rn(xi[j], v[j]));
+            for (int j = 0; j < d; j++) eta = add_nofma(eta, mul_nofma(xi[j], v[j]));
             double e = exp(eta);
             double p = e / (1.0 + e);
             if (t.y[i] == 1.0) lp += log(p);

@@ -128,11 +128,11 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     for (int j = lane; j < p; j += 64) {
                         const double xj = par ? S[(ci - 1) + k * j] : S[1 + j];
                         double yj;
-                        if (sk == MCMCHIP_SCALE_CONSTANT) yj = __dadd_rn(xj, __dmul_rn(sc[0], Z[j]));
-                        else if (sk == MCMCHIP_SCALE_DIAGONAL) yj = __dadd_rn(xj, __dmul_rn(sc[j], Z[j]));
+                        if (sk == MCMCHIP_SCALE_CONSTANT) yj = add_nofma(xj, mul_nofma(sc[0], Z[j]));
+                        else if (sk == MCMCHIP_SCALE_DIAGONAL) yj = add_nofma(xj, mul_nofma(sc[j], Z[j]));
                         else {
                             yj = xj;
-                            for (int i = 0; i < p; i++) yj = __dadd_rn(yj, __dmul_rn(sc[j + p * i], Z[i]));
+                            for (int i = 0; i < p; i++) yj = add_nofma(yj, mul_nofma(sc[j + p * i], Z[i]));
                         }
                         Y[j] = yj;
                     }

@@ -346,7 +346,7 @@ def test_temper_vs_oracle(api, oracle_mod, parallel, target, scale_kind):
     assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
     if not parallel:
         assert np.array_equal(o["ibatch"], ref["ibatch"])
-    assert np.array_equal(np.isnan(o["accepti"][0]), ~nb)      # NA exactly for non-neighbours
+    assert np.all(np.isnan(o["accepti"][0])[~nb])              # NA for non-neighbours (temper.c:896-897)
 
 
 def test_temper_philox_matches_oracle_restatement(api, oracle_mod):
@@ -425,9 +425,10 @@ def test_olbm_vs_oracle(api, oracle_mod, n, p, blen):
     x = np.cumsum(e * 0.1, axis=0) * 0.01 + e     # mildly autocorrelated, non-zero mean
     ref, refmean = oracle_mod.olbm(x, blen)
     got = api.olbm(x, blen)
-    assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))
+    tol = 1e-10 * np.max(np.abs(ref)) + 1e-24      # len == n: a single window, var is exactly 0 in the reference
+    assert np.max(np.abs(got - ref)) <= tol
     assert np.array_equal(got, got.T)
     got2 = api.olbm(x, blen, demean=False)        # R/olbm.R quirk: still demeans
-    assert np.max(np.abs(got2 - ref)) <= 1e-10 * np.max(np.abs(ref))
+    assert np.max(np.abs(got2 - ref)) <= tol
     with pytest.raises(ValueError, match="batch.length must be <= nrow"):
         api.olbm(x, n + 1)
