@@ -29,8 +29,12 @@
 #include "kernels.h"
 #include "philox.h"
 
-#define MFMA_TC 4          // observation tiles per LDS chunk
 typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define MFMA_NW 8          // wavefronts per workgroup (2 per SIMD: a second wave fills MFMA dependency gaps)
+#define MFMA_NC 2          // 16-chain tiles per wavefront -> 256 chains per workgroup
+// observation tiles per LDS chunk: 16 KB per buffer whatever d is
+static inline int mfma_tc(int ks) { return ks <= 2 ? 16 : (ks <= 4 ? 8 : (ks <= 8 ? 4 : 2)); }
 
 // ---------------------------------------------------------------------------------------------
 __global__ void tile_x_kernel(const double *__restrict__ x, const double *__restrict__ y, long n, int d,
@@ -59,7 +63,8 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
     if (t->dpad < 8) t->dpad = 8;
     t->ksteps = t->dpad / 4;
     long tiles = (t->n + 15) / 16;
-    tiles = ((tiles + MFMA_TC - 1) / MFMA_TC) * MFMA_TC;
+    const int tc = mfma_tc(t->ksteps);
+    tiles = ((tiles + tc - 1) / tc) * tc;
     t->ntiles = tiles;
     t->npad_rows = tiles * 16 - t->n;
     size_t bytes = (size_t)tiles * t->ksteps * 64 * sizeof(double);
@@ -72,40 +77,23 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int KS, int NC>
-__device__ __forceinline__ void epilogue_tile(const double4_t (&acc)[NC], double (&sum)[NC],
-                                              const double *sExp, const double *sLog)
+template <int KS, int NC, int NW, int TC>
+__global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__restrict__ xt,
+                                                               const double *__restrict__ prop, long ldc,
+                                                               double *__restrict__ partial,
+                                                               long tiles_per_split, long ntiles,
+                                                               const SoftplusTables *__restrict__ tab)
 {
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double eta = acc[c][r];
-            const double L = softplus_neg(fabs(eta), sExp, sLog);
-            sum[c] += fmin(eta, 0.0) - L;
-        }
-    }
-}
-
-template <int KS, int NC>
-__global__ __launch_bounds__(256, 1) void logdens_mfma_kernel(const double *__restrict__ xt,
-                                                              const double *__restrict__ prop, long ldc,
-                                                              double *__restrict__ partial,
-                                                              long tiles_per_split, long ntiles,
-                                                              const SoftplusTables *__restrict__ tab)
-{
-    constexpr int CHUNK = MFMA_TC * KS * 64;          // doubles per LDS buffer
-    __shared__ __attribute__((aligned(16))) double smem[2 * CHUNK + SP_EXP_N + 2 * SP_LOG_N];
+    constexpr int CHUNK = TC * KS * 64;               // doubles per LDS buffer (16 KB)
+    __shared__ __attribute__((aligned(16))) double smem[2 * CHUNK + 2 * SP_N];
     double *sX = smem;
-    double *sExp = smem + 2 * CHUNK;
-    double *sLog = sExp + SP_EXP_N;
+    double *sTab = smem + 2 * CHUNK;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < SP_EXP_N; i += 256) sExp[i] = tab->expT[i];
-    for (int i = threadIdx.x; i < 2 * SP_LOG_N; i += 256) sLog[i] = tab->logT[i];
+    for (int i = threadIdx.x; i < 2 * SP_N; i += NW * 64) sTab[i] = tab->e[i];
 
     // loop-invariant B fragments: Theta[k = 4ks + (lane>>4)][chain = chain0 + 16c + (lane&15)]
-    const long chain0 = ((long)blockIdx.x * 4 + wave) * 16 * NC;
+    const long chain0 = ((long)blockIdx.x * NW + wave) * 16 * NC;
     double b[KS][NC];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++)
@@ -116,35 +104,36 @@ __global__ __launch_bounds__(256, 1) void logdens_mfma_kernel(const double *__re
     const long t0 = (long)blockIdx.y * tiles_per_split;
     long t1 = t0 + tiles_per_split;
     if (t1 > ntiles) t1 = ntiles;
-    const long nchunks = (t1 - t0) / MFMA_TC;
+    const long nchunks = (t1 - t0) / TC;
     const double *gsrc = xt + (size_t)t0 * KS * 64;
 
-    // LDS-DMA: each wave moves its quarter of a chunk, 1 KiB (64 lanes x 16 B) per instruction
-    constexpr int PER_WAVE = CHUNK / 4;               // doubles
-    constexpr int NINST = PER_WAVE / 128;
+    // LDS-DMA staging: a chunk is CHUNK/128 pieces of 1 KiB (64 lanes x 16 B), dealt round-robin to the waves
+    constexpr int NPIECE = CHUNK / 128;
     auto stage = [&](long chunk, int buf) {
-        const double *g = gsrc + (size_t)chunk * CHUNK + wave * PER_WAVE + lane * 2;
-        double *l = sX + buf * CHUNK + wave * PER_WAVE;
+        const double *g = gsrc + (size_t)chunk * CHUNK + lane * 2;
+        double *l = sX + buf * CHUNK;
 #pragma unroll
-        for (int i = 0; i < NINST; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i * 128),
-                                             (__attribute__((address_space(3))) void *)(l + i * 128), 16, 0, 0);
+        for (int i = 0; i < (NPIECE + NW - 1) / NW; i++) {
+            const int piece = wave + i * NW;
+            if (piece < NPIECE)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + piece * 128),
+                                                 (__attribute__((address_space(3))) void *)(l + piece * 128), 16, 0, 0);
+        }
     };
 
     double sum[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) sum[c] = 0.0;
-    double4_t prev[NC];
 
     if (nchunks > 0) stage(0, 0);
-    __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the tables
+    __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the table
 
     for (long ch = 0; ch < nchunks; ch++) {
         const int buf = (int)(ch & 1);
         if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
         const double *xs = sX + buf * CHUNK + lane;
 #pragma unroll
-        for (int tt = 0; tt < MFMA_TC; tt++) {
+        for (int tt = 0; tt < TC; tt++) {
             double4_t acc[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -155,13 +144,18 @@ __global__ __launch_bounds__(256, 1) void logdens_mfma_kernel(const double *__re
                 for (int c = 0; c < NC; c++)
                     acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][c], acc[c], 0, 0, 0);
             }
-            if (!(ch == 0 && tt == 0)) epilogue_tile<KS, NC>(prev, sum, sExp, sLog);
+            // softplus epilogue straight from the accumulators: min(eta,0) - L(|eta|)
 #pragma unroll
-            for (int c = 0; c < NC; c++) prev[c] = acc[c];
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double eta = acc[c][r];
+                    sum[c] += fmin(eta, 0.0);
+                    sum[c] -= softplus_neg(fabs(eta), sTab);
+                }
         }
         __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
     }
-    if (nchunks > 0) epilogue_tile<KS, NC>(prev, sum, sExp, sLog);
 
     // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
 #pragma unroll
@@ -328,45 +322,49 @@ static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
 {
     MfmaPlan pl;
     pl.ks = t->ksteps;
-    pl.nc = (t->ksteps <= 8) ? 4 : 4;
-    long per_wg = 64L * pl.nc;
+    pl.nc = MFMA_NC;
+    const int tc = mfma_tc(pl.ks);
+    long per_wg = 16L * MFMA_NC * MFMA_NW;
     pl.chain_blocks = (nchain + per_wg - 1) / per_wg;
     pl.ldc = pl.chain_blocks * per_wg;
-    long chunks = t->ntiles / MFMA_TC;
-    // enough workgroups for >= 2 waves of the chip, but keep >= 8 chunks per workgroup so the
-    // B-fragment preload and the pipeline fill amortise
-    long want = (2L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;
-    if (want < 1) want = 1;
-    long maxsplit = chunks / 8 > 0 ? chunks / 8 : 1;
-    if (want > maxsplit) want = maxsplit;
-    if (want > 64) want = 64;
+    long chunks = t->ntiles / tc;
+    // one workgroup per CU (LDS-bound occupancy).  A grid that is a whole number of chip-fulls needs no
+    // observation split; otherwise split the observations until the tail round is small, keeping
+    // >= 8 chunks per workgroup so the B-fragment preload amortises.
+    long want = 1;
+    if (pl.chain_blocks % num_cu != 0) {
+        want = (4L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;
+        long maxsplit = chunks / 8 > 0 ? chunks / 8 : 1;
+        if (want > maxsplit) want = maxsplit;
+        if (want > 256) want = 256;
+    }
     long cps = (chunks + want - 1) / want;     // chunks per split
     pl.nsplit = (int)((chunks + cps - 1) / cps);
-    pl.tiles_per_split = cps * MFMA_TC;
+    pl.tiles_per_split = cps * tc;
     return pl;
 }
 
-template <int KS>
+template <int KS, int TC>
 static void launch_ld(const MfmaPlan &pl, const mcmchip_target *t, const double *prop, double *partial,
                       DeviceCtx *dc)
 {
-    dim3 grid((unsigned)pl.chain_blocks, (unsigned)pl.nsplit), block(256);
-    hipLaunchKernelGGL((logdens_mfma_kernel<KS, 4>), grid, block, 0, dc->stream, t->xt, prop, pl.ldc, partial,
-                       pl.tiles_per_split, t->ntiles, dc->d_tables);
+    dim3 grid((unsigned)pl.chain_blocks, (unsigned)pl.nsplit), block(MFMA_NW * 64);
+    hipLaunchKernelGGL((logdens_mfma_kernel<KS, MFMA_NC, MFMA_NW, TC>), grid, block, 0, dc->stream, t->xt, prop,
+                       pl.ldc, partial, pl.tiles_per_split, t->ntiles, dc->d_tables);
 }
 
 static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const double *prop, double *partial,
                           DeviceCtx *dc)
 {
     switch (pl.ks) {
-    case 2: launch_ld<2>(pl, t, prop, partial, dc); break;
-    case 4: launch_ld<4>(pl, t, prop, partial, dc); break;
-    case 6: launch_ld<6>(pl, t, prop, partial, dc); break;
-    case 8: launch_ld<8>(pl, t, prop, partial, dc); break;
-    case 10: launch_ld<10>(pl, t, prop, partial, dc); break;
-    case 12: launch_ld<12>(pl, t, prop, partial, dc); break;
-    case 14: launch_ld<14>(pl, t, prop, partial, dc); break;
-    case 16: launch_ld<16>(pl, t, prop, partial, dc); break;
+    case 2: launch_ld<2, 16>(pl, t, prop, partial, dc); break;
+    case 4: launch_ld<4, 8>(pl, t, prop, partial, dc); break;
+    case 6: launch_ld<6, 4>(pl, t, prop, partial, dc); break;
+    case 8: launch_ld<8, 4>(pl, t, prop, partial, dc); break;
+    case 10: launch_ld<10, 2>(pl, t, prop, partial, dc); break;
+    case 12: launch_ld<12, 2>(pl, t, prop, partial, dc); break;
+    case 14: launch_ld<14, 2>(pl, t, prop, partial, dc); break;
+    case 16: launch_ld<16, 2>(pl, t, prop, partial, dc); break;
     default: return set_error(MCMCHIP_EINVAL, "MFMA path supports d <= %d", MCMCHIP_MFMA_MAXD);
     }
     HIP_TRY(hipGetLastError());

