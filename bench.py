@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
-    ap.add_argument("--scale", type=float, default=2.5e-3)
+    ap.add_argument("--scale", type=float, default=4.0e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -174,6 +174,7 @@ void mcmchip_target_destroy(mcmchip_target *t)
     if (t->y) (void)hipFree(t->y);
     if (t->par) (void)hipFree(t->par);
     if (t->xt) (void)hipFree(t->xt);
+    if (t->colsum) (void)hipFree(t->colsum);
     delete t;
 }
 

@@ -134,6 +134,7 @@ struct mcmchip_target {
     int64_t ntiles = 0;     // 16-observation tiles (padded up to a multiple of MFMA_TILES_PER_CHUNK)
     int64_t npad_rows = 0;  // zero rows appended (each contributes exactly -L(0) = -ln 2)
     double *xt = nullptr;
+    double *colsum = nullptr;  // [dpad] column sums of the sign-folded X (sum_i eta_i = colsum . theta)
     int device = 0;
 };
 

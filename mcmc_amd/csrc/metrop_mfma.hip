@@ -57,6 +57,29 @@ __global__ void tile_x_kernel(const double *__restrict__ x, const double *__rest
     xt[idx] = v;
 }
 
+// column sums of the sign-folded X from the tiles: one workgroup per (kstep, k) column, fixed-order reduction
+__global__ __launch_bounds__(256) void tile_colsum_kernel(const double *__restrict__ xt, int ksteps, long ntiles,
+                                                          double *__restrict__ colsum)
+{
+    __shared__ double red[256];
+    const int col = blockIdx.x;                 // 0 .. dpad-1
+    const int ks = col >> 2, kk = col & 3;
+    double s = 0.0;
+    // element (tile t, row r) of column col sits at xt[((t*ksteps + ks)*64) + kk*16 + r]
+    for (long i = threadIdx.x; i < ntiles * 16; i += 256) {
+        const long t = i >> 4;
+        const int r = (int)(i & 15);
+        s += xt[((size_t)t * ksteps + ks) * 64 + kk * 16 + r];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) colsum[col] = red[0];
+}
+
 int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 {
     t->dpad = ((t->d + 7) / 8) * 8;
@@ -72,6 +95,9 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
     long total = tiles * t->ksteps * 64;
     hipLaunchKernelGGL(tile_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t->x, t->y,
                        (long)t->n, t->d, t->ksteps, tiles, t->xt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMalloc((void **)&t->colsum, (size_t)t->dpad * sizeof(double)));
+    hipLaunchKernelGGL(tile_colsum_kernel, dim3((unsigned)t->dpad), dim3(256), 0, s, t->xt, t->ksteps, tiles, t->colsum);
     HIP_TRY(hipGetLastError());
     return MCMCHIP_OK;
 }
@@ -121,9 +147,9 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         }
     };
 
-    double sum[NC];
+    double sum[NC], sabs[NC];     // sum of L(|eta|), sum of |eta|
 #pragma unroll
-    for (int c = 0; c < NC; c++) sum[c] = 0.0;
+    for (int c = 0; c < NC; c++) sum[c] = sabs[c] = 0.0;
 
     if (nchunks > 0) stage(0, 0);
     __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the table
@@ -144,14 +170,16 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
                 for (int c = 0; c < NC; c++)
                     acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][c], acc[c], 0, 0, 0);
             }
-            // softplus epilogue straight from the accumulators: min(eta,0) - L(|eta|)
+            // softplus epilogue straight from the accumulators.  min(eta,0) - L(|eta|) is split as
+            // (eta - |eta|)/2 - L: sum(eta) is linear in Theta (colsum . theta, added by the update
+            // kernel), so only |eta| and L are accumulated here.
 #pragma unroll
             for (int c = 0; c < NC; c++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const double eta = acc[c][r];
-                    sum[c] += fmin(eta, 0.0);
-                    sum[c] -= softplus_neg(fabs(eta), sTab);
+                    sabs[c] += fabs(eta);
+                    sum[c] += softplus_neg(sp_clamp_abs(eta), sTab);
                 }
         }
         __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
@@ -160,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        double v = sum[c];
+        double v = fma(0.5, sabs[c], sum[c]);          // partial = sum(|eta|)/2 + sum(L); the update kernel negates
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (lane < 16) partial[(size_t)blockIdx.y * ldc + chain0 + 16 * c + lane] = v;
@@ -183,6 +211,7 @@ struct UpdParams {
     const double *z, *u;
     unsigned long long seed, chain_offset, iter_offset;
     const double *partial;
+    const double *colsum;   // [dpad] column sums of the sign-folded X
     double *state, *prop;   // [dpad][ldc]
     double *cur, *acc, *acc_b, *buf;  // [ldc], [ldc], [ldc], [nout][ldc]
     double *batch, *accept_batch, *accept, *final_;  // chain-major outputs
@@ -231,11 +260,17 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     if (c >= q.nchain) return;
     const int d = q.d;
     const long ldc = q.ldc;
-    double ly = 0.0;
-    for (int s = 0; s < q.nsplit; s++) ly += q.partial[(size_t)s * ldc + c];
-    ly += q.pad_term;
-    double ss = 0.0;
-    for (int j = 0; j < d; j++) { const double v = q.prop[(size_t)j * ldc + c]; ss += v * v; }
+    // log density = sum_i [ (eta_i - |eta_i|)/2 - L(|eta_i|) ] - prior_c |theta|^2, with
+    // sum_i eta_i = colsum . theta (eta is linear in theta) and the rest from the MFMA kernel's partials
+    double part = 0.0;
+    for (int s = 0; s < q.nsplit; s++) part += q.partial[(size_t)s * ldc + c];
+    double ss = 0.0, lin = 0.0;
+    for (int j = 0; j < d; j++) {
+        const double v = q.prop[(size_t)j * ldc + c];
+        ss += v * v;
+        lin = fma(v, q.colsum[j], lin);
+    }
+    double ly = (0.5 * lin - part) + q.pad_term;
     ly -= ss * q.prior_c;
     if (q.logdens_out) { q.logdens_out[c] = ly; return; }
     if (ly == INFINITY) atomicOr(q.flag, FLAG_POSINF);
@@ -403,6 +438,7 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     q.rng_mode = p.rng_mode; q.z = p.z; q.u = p.u;
     q.seed = p.seed; q.chain_offset = p.chain_offset; q.iter_offset = p.iter_offset;
     q.partial = partial.as<double>();
+    q.colsum = t->colsum;
     q.state = state.as<double>(); q.prop = prop.as<double>();
     q.cur = cur.as<double>(); q.acc = acc.as<double>(); q.acc_b = acc_b.as<double>(); q.buf = buf.as<double>();
     q.batch = p.batch; q.accept_batch = p.accept_batch; q.accept = p.accept; q.final_ = p.final_;
@@ -451,6 +487,7 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
     q.prior_c = t->prior_c;
     q.nbatch = q.blen = q.nspac = 1;
     q.partial = partial.as<double>();
+    q.colsum = t->colsum;
     q.state = state.as<double>(); q.prop = prop.as<double>();
     q.logdens_out = out;
     hipLaunchKernelGGL(metrop_update_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q, -1L);

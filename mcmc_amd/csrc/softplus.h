@@ -38,11 +38,25 @@ struct SoftplusTables {
 SP_HD double sp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 SP_HD int32_t sp_lo(double x) { int64_t b; memcpy(&b, &x, 8); return (int32_t)b; }
 
-// tab may live in LDS (device) or plain memory (host)
-SP_HD double softplus_neg(double a_in, const double *tab)
+// min(|eta|, SP_AMAX).  On the device one v_min_f64 with the |.| source modifier: written as
+// inline asm because the compiler's fmin() first canonicalises its operand (an extra
+// v_max_f64 x,x per call) when it cannot prove the MFMA result is not a signalling NaN.
+SP_HD double sp_clamp_abs(double eta)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double a;
+    asm("v_min_f64 %0, |%1|, %2" : "=v"(a) : "v"(eta), "s"((double)SP_AMAX));
+    return a;
+#else
+    const double a = fabs(eta);
+    return a < (double)SP_AMAX ? a : (double)SP_AMAX;
+#endif
+}
+
+// a must already be clamped to [0, SP_AMAX] (sp_clamp_abs); tab may live in LDS or host memory
+SP_HD double softplus_neg(double a, const double *tab)
 {
     const double SHIFT = 6755399441055744.0;   // 1.5 * 2^52: low mantissa bits of (x + SHIFT) = rint(x)
-    const double a = a_in < (double)SP_AMAX ? a_in : (double)SP_AMAX;
     const double jd = sp_fma(a, (double)SP_INV_H, SHIFT);
     const int32_t j = sp_lo(jd);
     const double jf = jd - SHIFT;

@@ -4,7 +4,7 @@ static SoftplusTables T; static int init = 0;
 extern "C" void softplus_host(const double *a, double *out, long n)
 {
     if (!init) { softplus_tables_init(&T); init = 1; }
-    for (long i = 0; i < n; i++) out[i] = softplus_neg(a[i], T.e);
+    for (long i = 0; i < n; i++) out[i] = softplus_neg(sp_clamp_abs(a[i]), T.e);
 }
 extern "C" void softplus_ref(const double *a, double *out, double *unused, long n)
 {
