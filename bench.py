@@ -134,6 +134,15 @@ def main():
         elapsed = float(tmax.item())
 
     kname, kms, klaunch = api.last_kernel_time()
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
+    # process, so the recorded rocprofv3 measurement of the same workload is reported (or null)
+    traffic = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        if rec["workload"] == {"n": a.n, "d": a.d, "chains_per_gpu": a.chains}:
+            traffic = rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         flops_per_launch = 2.0 * a.n * a.d * Cn
         achieved = flops_per_launch / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
@@ -152,7 +161,8 @@ def main():
                        "accept_rate": float(summ[0].item()),
                        "note": "timed call = %d iterations + the call's initial-state density evaluation" % a.steps},
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
                          "launch_ms": kms, "launches_timed": klaunch,
                          "flops_per_launch": flops_per_launch},
         }
