@@ -14,8 +14,11 @@
  *     (same wording as the reference's error() call where one exists) is
  *     retrievable with mcmchip_last_error() from the same thread.
  *   - `device_ptrs == 0`: data pointers are host memory, the library stages
- *     them through HBM.  `device_ptrs == 1`: data pointers are device (HIP)
- *     memory on the current device, nothing crosses PCIe.
+ *     them through HBM.  `device_ptrs == 1`: the bulk data pointers (initial, z, u, unif,
+ *     norm, x of initseq/olbm and the sampler outputs) are device (HIP) memory on the
+ *     current device, nothing crosses PCIe.  Small control arrays (scale, out_index,
+ *     neighbors) and the small results of initseq/olbm (mean, var, Gamma vectors, n_out)
+ *     are always host memory.
  *   - inputs are never modified (reference: metrop.c:67-70 duplicates
  *     `initial`); outputs are caller-allocated.
  *   - batched extension: the reference runs ONE chain per call; here a call
