@@ -60,7 +60,7 @@ def cpu_baseline(X, y, beta, scale, threads, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=64)
@@ -76,8 +76,9 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # launched by torch.distributed.run
+    if use_dist:
+        dist.init_process_group("nccl", device_id=dev)              # "nccl" is RCCL on ROCm
 
     from mcmc_amd import abi, api
     api.init(local_rank)
@@ -113,22 +114,26 @@ def main():
         _, _, state, off = run(a.warmup, init, 0)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if use_dist:                                        # create the RCCL communicator outside the timed region
+        warm = [torch.empty(1 + d, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(warm, torch.zeros(1 + d, dtype=torch.float64, device=dev))
 
     barrier()
     t0 = time.perf_counter()
     acc, batch, state, off = run(a.steps, state, off)
     # the one collective of the path: per-rank summaries (acceptance rate, mean of the batch means)
     summ = torch.cat([acc.mean().reshape(1), batch.mean(dim=(0, 1))])
-    if world > 1:
+    if use_dist:
         allsum = [torch.empty_like(summ) for _ in range(world)]
         dist.all_gather(allsum, summ)
         summ = torch.stack(allsum).mean(dim=0)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -173,7 +178,7 @@ def main():
             except Exception as e:          # the baseline is a reported extra, never the product path
                 res["cpu_baseline"] = {"value": None, "error": str(e)}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

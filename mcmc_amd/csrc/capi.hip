@@ -153,9 +153,28 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
         }
         if (desc->npar > 0 && desc->par) {
             t->npar = desc->npar;
-            if (hipMalloc((void **)&t->par, (size_t)desc->npar * 8) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc failed"); break; }
-            if (hipMemcpyAsync(t->par, desc->par, (size_t)desc->npar * 8, kind, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of descriptor parameters failed"); break; }
-            if (!desc_device_ptrs) t->host_par.assign(desc->par, desc->par + desc->npar);
+            t->host_par.resize((size_t)desc->npar);
+            if (desc_device_ptrs) {
+                if (hipMemcpy(t->host_par.data(), desc->par, (size_t)desc->npar * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of descriptor parameters failed"); break; }
+            } else {
+                memcpy(t->host_par.data(), desc->par, (size_t)desc->npar * 8);
+            }
+            if (desc->kind == MCMCHIP_T_WITCH) {
+                // the witch's hat takes only two values per component (tests/temp-par-witch.R:24-40): evaluate
+                // them once, on the host, with the same libm expressions as the reference's closure, and ship
+                // them behind the bounds: par = bnd[k], inside[k], corner[k]
+                const int64_t k = desc->npar;
+                const int p = desc->d;
+                for (int64_t i = 0; i < k; i++) {
+                    const double bnd = t->host_par[(size_t)i];
+                    if (!(bnd > 0.0 && bnd < 1.0)) { rc = set_error(MCMCHIP_EINVAL, "witch.which[%d] must be in (0, 1)", (int)i + 1); break; }
+                }
+                if (rc) break;
+                for (int64_t i = 0; i < k; i++) t->host_par.push_back(-(p + 1) * log(2) - log1p(-pow(1 - t->host_par[(size_t)i], p)));
+                for (int64_t i = 0; i < k; i++) t->host_par.push_back(-(p + 1) * log(2) - p * log(1 - t->host_par[(size_t)i]));
+            }
+            if (hipMalloc((void **)&t->par, t->host_par.size() * 8) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc failed"); break; }
+            if (hipMemcpyAsync(t->par, t->host_par.data(), t->host_par.size() * 8, hipMemcpyHostToDevice, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of descriptor parameters failed"); break; }
         } else if (!is_logistic(desc->kind) && desc->kind != MCMCHIP_T_BALL) {
             rc = set_error(MCMCHIP_EINVAL, "descriptor kind %d needs a parameter block", desc->kind);
             break;

@@ -209,18 +209,19 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
 // ---------------------------------------------------------------------------------------------
 // log density of a batch of states (replaces logh(), metrop.c:303-323): 16 lanes per state
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logdens_stream_kernel(TargetView tv, int temper_kind, long npar_unused,
+__global__ __launch_bounds__(256) void logdens_stream_kernel(TargetView tv, int temper_kind, long ncomp_l,
                                                              const double *states, long nchain, double *out)
 {
     constexpr int G = 16;
     const int g = threadIdx.x % G;
+    const int ncomp = (int)ncomp_l;
     long c = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
     const bool live = c < nchain;
     if (!live) c = nchain - 1;
     double v;
     if (temper_kind) {
         const double *s = states + (size_t)c * (tv.d + 1);
-        v = lud_temper(tv.kind, tv.d, tv.par, (int)s[0], s + 1);
+        v = lud_temper(tv.kind, tv.d, tv.par, ncomp, (int)s[0], s + 1);
     } else {
         v = lud_group<G>(tv, states + (size_t)c * tv.d, g);
     }
@@ -235,7 +236,8 @@ int launch_logdens_stream(const mcmchip_target *t, const double *states, long nc
     tv.prior_c = t->prior_c;
     int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX);
     dim3 grid((unsigned)((nchain + 15) / 16)), block(256);
-    hipLaunchKernelGGL(logdens_stream_kernel, grid, block, 0, s, tv, temper_kind, 0L, states, nchain, out);
+    hipLaunchKernelGGL(logdens_stream_kernel, grid, block, 0, s, tv, temper_kind,
+                       (long)(t->kind == MCMCHIP_T_WITCH ? t->npar : 0), states, nchain, out);
     HIP_TRY(hipGetLastError());
     return MCMCHIP_OK;
 }

@@ -144,19 +144,22 @@ template <int G> __device__ double lud_group(const TargetView &t, const double *
 
 // temper targets; state = (i, theta[p]) with 1-based component i.  Small p: every lane of the
 // caller evaluates the whole thing (no cooperation), so this is a plain scalar function.
-__device__ inline double lud_temper(int kind, int p, const double *par, int i, const double *th)
+__device__ inline double lud_temper(int kind, int p, const double *par, int ncomp, int i, const double *th)
 {
     switch (kind) {
     case MCMCHIP_T_WITCH: {
-        // tests/temp-par-witch.R:24-40
-        for (int j = 0; j < p; j++)
-            if (fabs(th[j]) > 1.0) return -INFINITY;
-        double bnd = par[i - 1];
-        int all = 1;
-        for (int j = 0; j < p; j++)
-            if (!(fabs(th[j]) > bnd)) all = 0;
-        if (all) return -(p + 1) * log(2.0) - p * log(1 - bnd);
-        return -(p + 1) * log(2.0) - log1p(-pow(1 - bnd, (double)p));
+        // tests/temp-par-witch.R:24-40.  par = bnd[k], inside[k], corner[k]: the two values the density
+        // takes in component i were evaluated on the host (capi.hip) with the reference's expressions
+        //   inside = -(d+1)log2 - log1p(-(1-bnd)^d),  corner = -(d+1)log2 - d log(1-bnd)
+        bool out = false, all = true;
+        const double bnd = par[i - 1];
+        for (int j = 0; j < p; j++) {
+            const double a = fabs(th[j]);
+            out |= a > 1.0;
+            all &= a > bnd;
+        }
+        if (out) return -INFINITY;
+        return all ? par[2 * ncomp + i - 1] : par[ncomp + i - 1];
     }
     case MCMCHIP_T_TEMPERED_NORMMIX: {
         int k = (int)par[0];

@@ -27,7 +27,7 @@
 #define TEMPER_MAXK 64
 
 struct TemperLds {
-    int state, L, Y, Z, buf, ibuf, axn, axd, ain, aid, nn, nb, end;  // offsets in 8-byte words
+    int state, L, Y, Z, buf, ibuf, axn, axd, ain, aid, nn, nb, ubuf, zbuf, end;  // offsets in 8-byte words
 };
 
 __device__ __forceinline__ int pick1(double u, int m)
@@ -50,6 +50,8 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     unsigned *axn = (unsigned *)(lds + lay.axn), *axd = (unsigned *)(lds + lay.axd);
     unsigned *ain = (unsigned *)(lds + lay.ain), *aid = (unsigned *)(lds + lay.aid);
     int *nn = (int *)(lds + lay.nn), *nb = (int *)(lds + lay.nb);
+    double *Ubuf = lds + lay.ubuf, *Zbuf = lds + lay.zbuf;   // Philox draws of the next 64 iterations
+    const int pz = (p + 1) & ~1;
 
     for (int i = lane; i < nstate; i += 64) S[i] = q.initial[(size_t)e * nstate + i];
     for (int i = lane; i < k; i += 64) {
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
         for (int i = lane; i < k; i += 64) {
             double th[TEMPER_MAXP];
             for (int j = 0; j < p; j++) th[j] = S[i + k * j];
-            double v = lud_temper(q.kind, p, q.par, i + 1, th);
+            double v = lud_temper(q.kind, p, q.par, k, i + 1, th);
             L[i] = v;
             if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
             else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
         __syncthreads();
         if (lane == 0) {
             int i = (int)S[0];
-            double v = lud_temper(q.kind, p, q.par, i, S + 1);
+            double v = lud_temper(q.kind, p, q.par, k, i, S + 1);
             L[i - 1] = v;
             if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
             else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
@@ -102,11 +104,30 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
             for (int is = 0; is < q.nspac; is++, it++) {
                 const unsigned long long git = q.iter_offset + (unsigned long long)it;
                 double u0, u1, u2 = 0.0, u3 = 0.0;   // which, choose1, choose2, hastings
-                const double *up = inj ? q.unif + ((size_t)e * niter + it) * 4 : nullptr;
-                if (inj) { u0 = up[0]; u1 = up[1]; }
-                else philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, git, 0u, u0, u1);
+                const double *up;
+                if (inj) {
+                    up = q.unif + ((size_t)e * niter + it) * 4;
+                } else {
+                    // device RNG: every 64 iterations the 64 lanes draw, in one pass, all Philox blocks of the
+                    // next 64 iterations (lane t <-> iteration it + t) into LDS, so the dependent chain of an
+                    // iteration only contains LDS reads.  Same counter addressing as a draw-on-demand scheme.
+                    if ((it & 63) == 0) {
+                        const unsigned long long g2 = git + (unsigned long long)lane;
+                        double a, b;
+                        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 0u, a, b);
+                        Ubuf[lane * 4 + 0] = a; Ubuf[lane * 4 + 1] = b;
+                        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 1u, a, b);
+                        Ubuf[lane * 4 + 2] = a; Ubuf[lane * 4 + 3] = b;
+                        for (int j2 = 0; 2 * j2 < p; j2++) {
+                            philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, g2, (uint32_t)(2 + j2), a, b);
+                            Zbuf[lane * pz + 2 * j2] = a; Zbuf[lane * pz + 2 * j2 + 1] = b;
+                        }
+                        __syncthreads();
+                    }
+                    up = Ubuf + (it & 63) * 4;
+                }
+                u0 = up[0]; u1 = up[1];
                 const bool within = u0 < 0.5;          // temper.c:537-538
-                bool have23 = false;
                 double lh;
                 int ci, cj = 0;                        // 1-based components
                 double ly = 0.0, sco = 0.0, spr = 0.0;
@@ -116,12 +137,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     if (inj) {
                         for (int j = lane; j < p; j += 64) Z[j] = q.norm[((size_t)e * niter + it) * p + j];
                     } else {
-                        for (int j2 = lane; 2 * j2 < p; j2 += 64) {
-                            double za, zb;
-                            philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, git, (uint32_t)(2 + j2), za, zb);
-                            Z[2 * j2] = za;
-                            if (2 * j2 + 1 < p) Z[2 * j2 + 1] = zb;
-                        }
+                        for (int j = lane; j < p; j += 64) Z[j] = Zbuf[(it & 63) * pz + j];
                     }
                     __syncthreads();
                     const double *sc = q.scale + (slist ? (size_t)(ci - 1) * slen1 : 0);
@@ -137,32 +153,30 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                         Y[j] = yj;
                     }
                     __syncthreads();
-                    ly = lud_temper(q.kind, p, q.par, ci, Y);
+                    ly = lud_temper(q.kind, p, q.par, k, ci, Y);
                     lh = ly - L[ci - 1];
                     if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
                 } else if (par) {
-                    if (inj) u2 = up[2];
-                    else { philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, git, 1u, u2, u3); have23 = true; }
+                    u2 = up[2];
                     ci = pick1(u1, k);
                     cj = nb[(ci - 1) * maxnn + pick1(u2, nn[ci - 1]) - 1] + 1;
                     double xi[TEMPER_MAXP], xj[TEMPER_MAXP];
                     for (int j = 0; j < p; j++) { xi[j] = S[(ci - 1) + k * j]; xj[j] = S[(cj - 1) + k * j]; }
-                    sco = lud_temper(q.kind, p, q.par, cj, xi);   // (j, x_i) first (temper.c:738-739)
-                    spr = lud_temper(q.kind, p, q.par, ci, xj);   // (i, x_j)
+                    sco = lud_temper(q.kind, p, q.par, k, cj, xi);   // (j, x_i) first (temper.c:738-739)
+                    spr = lud_temper(q.kind, p, q.par, k, ci, xj);   // (i, x_j)
                     lh = spr + sco - L[cj - 1] - L[ci - 1];       // temper.c:742-744
                     if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (lane == 0) atomicOr(q.flag, FLAG_NAN); }
                 } else {
                     ci = (int)S[0];
                     cj = nb[(ci - 1) * maxnn + pick1(u1, nn[ci - 1]) - 1] + 1;
-                    ly = lud_temper(q.kind, p, q.par, cj, S + 1);
+                    ly = lud_temper(q.kind, p, q.par, k, cj, S + 1);
                     lh = ly - L[ci - 1] + log((double)nn[ci - 1]) - log((double)nn[cj - 1]);   // temper.c:810-812
                     if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
                 }
                 if (isnan(lh) || (isinf(lh) && lh > 0)) { if (lane == 0) atomicOr(q.flag, FLAG_HASTINGS); lh = -INFINITY; }
                 bool accept = true;
                 if (lh < 0.0) {                                   // temper.c:582-587
-                    if (inj) u3 = up[3];
-                    else if (!have23) philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, git, 1u, u2, u3);
+                    u3 = up[3];
                     accept = u3 < exp(lh);
                 }
                 __syncthreads();   // every lane has read S / L / Y for this decision
@@ -263,6 +277,8 @@ int launch_temper(const TemperDev &q, hipStream_t s)
     lay.aid = o; o += (k * maxnn + 1) / 2;
     lay.nn = o; o += (k + 1) / 2;
     lay.nb = o; o += (k * maxnn + 1) / 2;
+    lay.ubuf = o; o += 64 * 4;
+    lay.zbuf = o; o += 64 * ((p + 1) & ~1);
     lay.end = o;
     size_t bytes = (size_t)o * 8;
     if (bytes > 64 * 1024) return set_error(MCMCHIP_EINVAL, "tempering state (%zu bytes) does not fit the LDS budget", bytes);

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline bench): BASELINE.json configs 2, 4 and a reduced 5.
+Prints one JSON line per config.  usage: python tools/bench_other.py [c2] [c4] [c5]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from mcmc_amd import abi, api  # noqa: E402
+
+
+def c2():
+    """logit posterior (n=100, d=5), 4096 chains, device Philox, 10 000 iterations per chain"""
+    import oracle
+    from rhelpers import glm_binomial, load_logit
+    X, y = load_logit()
+    mle = glm_binomial(X, y)
+    Cn = 4096
+    init = mle + 0.05 * np.random.default_rng(42).standard_normal((Cn, 5))
+    tg = api.logistic_target(X, y)
+    api.metrop(tg, init, 100, scale=0.4, seed=1)
+    nb = 10000
+    t0 = time.perf_counter()
+    o = api.metrop(tg, init, nb, scale=0.4, seed=1)
+    el = time.perf_counter() - t0
+    name, kms, kn = api.last_kernel_time()
+    ot = oracle.Target(abi.T_LOGISTIC, 5, x=X, y=y, prior_c=0.125)
+    t0 = time.perf_counter()
+    oracle.metrop(ot, init[:64], 2000, scale=0.4, seed=1, nthreads=16)
+    cel = time.perf_counter() - t0
+    return {"config": "C2 logit 100x5, 4096 chains x %d iterations, Philox" % nb, "chain_iter_per_s": Cn * nb / el,
+            "kernel": name, "kernel_ms": kms, "accept": float(o["accept"].mean()),
+            "softplus_evals_per_s": Cn * nb * 100 / (kms * 1e-3),
+            "cpu_oracle_16thr_chain_iter_per_s": 64 * 2000 / cel}
+
+
+def c4():
+    """parallel tempering, k = 64 temperatures x 1024 ensembles (witch's hat p=3; tempered bimodal mixture p=2)"""
+    import oracle
+    out = []
+    k, E = 64, 1024
+    i, j = np.indices((k, k))
+    nb = np.abs(i - j) == 1
+    for name in ("witch", "mixture"):
+        if name == "witch":
+            p = 3
+            par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.linspace(0, 5, k) / p)
+            K, x0 = abi.T_WITCH, np.zeros(p)
+        else:
+            p = 2
+            par = np.concatenate([[float(k)], np.geomspace(1.0, 0.01, k),
+                                  abi.normmix_par([0.5, 0.5], [[-4.0, -4.0], [4.0, 4.0]], 1.0)])
+            K, x0 = abi.T_TEMPERED_NORMMIX, np.array([4.0, 4.0])
+        tg = api.Target(K, p, par=par)
+        init = np.tile(x0, (E, k, 1))
+        api.temper(tg, init, nb, 2, 5, 5, 0.3, parallel=True, seed=3)
+        nbatch, blen, nspac = 100, 10, 20
+        t0 = time.perf_counter()
+        o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3, parallel=True, seed=3)
+        el = time.perf_counter() - t0
+        kn, kms, _ = api.last_kernel_time()
+        niter = nbatch * blen * nspac
+        ot = oracle.Target(K, p, par=par)
+        t0 = time.perf_counter()
+        oracle.temper(ot, init[:16], nb, 20, blen, nspac, 0.3, parallel=True, seed=3, nthreads=16)
+        cel = time.perf_counter() - t0
+        out.append({"config": "C4 temper parallel %s k=64 p=%d, 1024 ensembles x %d iterations" % (name, p, niter),
+                    "ensemble_iter_per_s": E * niter / el, "kernel": kn, "kernel_ms": kms,
+                    "acceptx_mean": float(np.nanmean(o["acceptx"])), "accepti_mean": float(np.nanmean(o["accepti"])),
+                    "cpu_oracle_16thr_ensemble_iter_per_s": 16 * 20 * blen * nspac / cel})
+    return out
+
+
+def c5():
+    """initseq + olbm on AR(1) columns resident in HBM (reduced size: n = 4e6 x p = 32 = 1 GB)"""
+    import torch
+    from scipy.signal import lfilter
+    n, p = 4_000_000, 32
+    rng = np.random.default_rng(5)
+    rho = 0.5 + 0.49 * np.arange(p) / (p - 1)
+    x = np.empty((p, n))                       # column-major n x p
+    for c in range(p):
+        x[c] = lfilter([1.0], [1.0, -rho[c]], rng.standard_normal(n))
+    x -= x.mean(axis=1, keepdims=True)
+    api.init()
+    L = api.load_library()
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x).to(dev)
+    torch.cuda.synchronize()
+    res = []
+    cap = 8192
+    n_out = np.zeros(p, dtype=np.int64)
+    g0, vp, vd, vc = (np.empty(p) for _ in range(4))
+    Gp, Gd, Gc = (np.empty((p, cap)) for _ in range(3))
+    for rep in range(2):
+        t0 = time.perf_counter()
+        rc = L.mcmchip_initseq(xd.data_ptr(), n, p, 1, cap, n_out.ctypes.data, g0.ctypes.data, Gp.ctypes.data,
+                               Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data, vd.ctypes.data, vc.ctypes.data)
+        el = time.perf_counter() - t0
+        assert rc == 0, L.mcmchip_last_error()
+    kn, kms, klaunch = api.last_kernel_time()
+    lags = 2 * n_out
+    res.append({"config": "C5r initseq n=%d p=%d (HBM resident)" % (n, p), "seconds": el, "kernel": kn,
+                "kernel_ms_avg": kms, "kernel_launches": klaunch, "max_lag_pairs": int(n_out.max()),
+                "useful_lag_products_per_s": float((lags * n).sum() / el),
+                "var_con_over_gamma0": [float(v) for v in (vc / g0)[:4]]})
+    mean = np.zeros(p)
+    var = np.empty((p, p))
+    for blen in (1000,):
+        for rep in range(2):
+            t0 = time.perf_counter()
+            rc = L.mcmchip_olbm(xd.data_ptr(), n, p, blen, mean.ctypes.data, var.ctypes.data, 0, 1)
+            el = time.perf_counter() - t0
+            assert rc == 0, L.mcmchip_last_error()
+        kn, kms, _ = api.last_kernel_time()
+        res.append({"config": "C5r olbm n=%d p=%d len=%d (HBM resident)" % (n, p, blen), "seconds": el,
+                    "kernel": kn, "kernel_ms": kms, "algorithmic_GBps": 8.0 * n * p / (kms * 1e-3) / 1e9,
+                    "var00": float(var[0, 0])})
+    return res
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c4", "c5"]
+    for w in which:
+        r = {"c2": c2, "c4": c4, "c5": c5}[w]()
+        for line in (r if isinstance(r, list) else [r]):
+            print(json.dumps(line))
