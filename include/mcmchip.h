@@ -173,6 +173,7 @@ typedef struct mcmchip_temper_args {
     const double *norm;
     uint64_t seed, ens_offset, iter_offset;
     int32_t device_ptrs;
+    int32_t debug;                   /* fill the debug trace (temper.c:282-464, vignettes/debug.Rnw:64-243) */
 } mcmchip_temper_args;
 
 typedef struct mcmchip_temper_out {
@@ -183,6 +184,18 @@ typedef struct mcmchip_temper_out {
     double *accepti;   /* nens x (k x k column-major); NaN (reference: NA_REAL) for non-neighbours (temper.c:892-897) */
     double *final;     /* same shape as initial */
     uint64_t iter_offset_out;
+    /* debug trace, NULL unless args.debug.  Per ensemble, niter-major like the reference:
+     * element (iter, j) at [iter + niter*j] (temper.c:533,591,604); NaN where the reference stores NA */
+    int32_t *which;          /* nens x niter            : 1 = within-component update (temper.c:541) */
+    double *unif_which;      /* nens x niter */
+    double *state;           /* nens x niter x nstate   : state BEFORE the update (temper.c:528-535) */
+    double *log_hastings;    /* nens x niter */
+    double *unif_hastings;   /* nens x niter            : NaN unless log hastings < 0 (temper.c:583-587) */
+    double *proposal;        /* nens x niter x (p+1)    : (i, y) | swap: (j, x_j) | jump: (j, x) */
+    int32_t *acceptd;        /* nens x niter */
+    double *norm;            /* nens x niter x p        : NaN for swap/jump iterations (temper.c:762,833) */
+    double *unif_choose;     /* parallel: nens x niter x 2 (second NaN for within, temper.c:607-608); serial: nens x niter */
+    double *coproposal;      /* parallel only: nens x niter x (p+1) : (i, x_i) (temper.c:597,728) */
 } mcmchip_temper_out;
 
 /* ------------------------------------------------------------------ */

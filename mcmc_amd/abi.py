@@ -94,6 +94,7 @@ class TemperArgs(C.Structure):
         ("ens_offset", C.c_uint64),
         ("iter_offset", C.c_uint64),
         ("device_ptrs", C.c_int32),
+        ("debug", C.c_int32),
     ]
 
 
@@ -105,6 +106,16 @@ class TemperOut(C.Structure):
         ("accepti", C.c_void_p),
         ("final", C.c_void_p),
         ("iter_offset_out", C.c_uint64),
+        ("which", C.c_void_p),
+        ("unif_which", C.c_void_p),
+        ("state", C.c_void_p),
+        ("log_hastings", C.c_void_p),
+        ("unif_hastings", C.c_void_p),
+        ("proposal", C.c_void_p),
+        ("acceptd", C.c_void_p),
+        ("norm", C.c_void_p),
+        ("unif_choose", C.c_void_p),
+        ("coproposal", C.c_void_p),
     ]
 
 
@@ -300,7 +311,7 @@ class TemperCall:
     """numpy-backed argument/result block for one mcmchip_temper / orc_temper call"""
 
     def __init__(self, p, initial, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=RNG_PHILOX,
-                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None):
+                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None, debug=False):
         nb = np.asarray(neighbors)
         if nb.ndim != 2:
             raise ValueError('argument "neighbors" must be matrix')
@@ -337,12 +348,27 @@ class TemperCall:
         self.acceptx = np.empty((E, k))
         self.accepti = np.empty((E, k, k))                         # column-major k x k per ensemble
         self.final = np.empty((E, nstate))
+        self.debug = bool(debug)
+        self.nstate = nstate
+        T = self.niter
+        dbg = {}
+        if self.debug:
+            dbg = dict(which=np.empty((E, T), dtype=np.int32), unif_which=np.empty((E, T)),
+                       state=np.empty((E, nstate, T)), log_hastings=np.empty((E, T)),
+                       unif_hastings=np.empty((E, T)), proposal=np.empty((E, p + 1, T)),
+                       acceptd=np.empty((E, T), dtype=np.int32), norm=np.empty((E, p, T)),
+                       unif_choose=np.empty((E, 2, T)) if self.parallel else np.empty((E, T)),
+                       coproposal=np.empty((E, p + 1, T)) if self.parallel else None)
+        self.dbg = dbg
         self.args = TemperArgs(E, k, int(self.parallel), self.nbatch, self.blen, self.nspac,
                                np_ptr(self.neighbors), np_ptr(self.initial), self.scale_kind,
                                np_ptr(self.scale), int(rng_mode), np_ptr(self.unif), np_ptr(self.norm),
-                               int(seed), int(ens_offset), int(iter_offset), 0)
+                               int(seed), int(ens_offset), int(iter_offset), 0, int(self.debug))
         self.out = TemperOut(np_ptr(self.batch), np_ptr(self.ibatch), np_ptr(self.acceptx),
-                             np_ptr(self.accepti), np_ptr(self.final), 0)
+                             np_ptr(self.accepti), np_ptr(self.final), 0,
+                             *[np_ptr(dbg.get(n)) for n in ("which", "unif_which", "state", "log_hastings",
+                                                            "unif_hastings", "proposal", "acceptd", "norm",
+                                                            "unif_choose", "coproposal")])
 
     def result(self):
         E, k, p = self.nens, self.k, self.p
@@ -357,4 +383,19 @@ class TemperCall:
             r["final"] = self.final.reshape(E, p, k).transpose(0, 2, 1) if self.parallel else self.final
         if not self.parallel:
             r["ibatch"] = np.transpose(self.ibatch, (0, 2, 1))
+        if self.debug:
+            d = self.dbg
+            r["which"] = d["which"] != 0
+            r["unif.which"] = d["unif_which"]
+            # niter x nstate (serial) or niter x k x p (parallel), like the reference's arrays
+            st = np.transpose(d["state"], (0, 2, 1))
+            r["state"] = st.reshape(E, self.niter, p, k).transpose(0, 1, 3, 2) if self.parallel else st
+            r["log.hastings"] = d["log_hastings"]
+            r["unif.hastings"] = d["unif_hastings"]
+            r["proposal"] = np.transpose(d["proposal"], (0, 2, 1))
+            r["acceptd"] = d["acceptd"] != 0
+            r["norm"] = np.transpose(d["norm"], (0, 2, 1))
+            r["unif.choose"] = np.transpose(d["unif_choose"], (0, 2, 1)) if self.parallel else d["unif_choose"]
+            if self.parallel:
+                r["coproposal"] = np.transpose(d["coproposal"], (0, 2, 1))
         return r

@@ -212,7 +212,8 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
     initial  parallel: k x p matrix (or nens x k x p); serial: c(i, x) (or nens x (1+p))
     Returns the reference's names: lud, neighbors, nbatch, blen, nspac, scale, outfun, debug,
     parallel, initial.seed, final.seed, time, batch, acceptx, accepti, initial, final [, ibatch].
-    outfun functions and debug traces are not available on the device path.
+    outfun functions are not available on the device path; debug = TRUE returns the reference's trace
+    (which, unif.which, state, log.hastings, unif.hastings, proposal, acceptd, norm, unif.choose[, coproposal]).
     """
     if isinstance(obj, dict):
         prev = obj
@@ -224,6 +225,7 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
         nspac = prev["nspac"] if nspac is None else nspac
         scale = prev["scale"] if scale is None else scale
         parallel = prev["parallel"] if parallel is None else parallel
+        debug = prev["debug"] if debug is None else debug
         seed = prev["final.seed"][0] if seed is None else seed
         _iter_offset = prev["final.seed"][1]
         ens_offset = prev["final.seed"][2]
@@ -233,12 +235,11 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
     nspac = 1 if nspac is None else nspac
     scale = 1 if scale is None else scale
     parallel = False if parallel is None else parallel
+    debug = False if debug is None else debug
     if not isinstance(target, Target) or not target.is_temper_kind:
         raise TypeError('argument "obj" must be a tempering Target or a previous result')
     if outfun is not None:
         raise NotImplementedError("temper: outfun functions cannot run on the device path")
-    if debug:
-        raise NotImplementedError("temper: debug traces are not produced by the device path")
     init_arr = np.asarray(initial, dtype=np.float64)
     single = init_arr.ndim == (2 if parallel else 1)
     if unif is not None or norm is not None:
@@ -249,7 +250,7 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
             seed = int.from_bytes(os.urandom(8), "little")
     call = abi.TemperCall(target.d, init_arr, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=mode,
                           unif=unif, norm=norm, seed=seed or 0, ens_offset=ens_offset,
-                          iter_offset=_iter_offset)
+                          iter_offset=_iter_offset, debug=debug)
     t0 = time.perf_counter()
     _check(load_library().mcmchip_temper(target.handle, C.addressof(call.args), C.addressof(call.out)))
     elapsed = time.perf_counter() - t0
@@ -259,13 +260,17 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
         return a[0] if single else a
 
     out = {"lud": target, "neighbors": np.asarray(neighbors, dtype=bool), "nbatch": int(nbatch),
-           "blen": int(blen), "nspac": int(nspac), "scale": scale, "outfun": None, "debug": False,
+           "blen": int(blen), "nspac": int(nspac), "scale": scale, "outfun": None, "debug": bool(debug),
            "parallel": bool(parallel), "initial.seed": (seed, _iter_offset, ens_offset),
            "final.seed": (seed, r["iter_offset"], ens_offset), "time": elapsed,
            "batch": sq(r["batch"]), "acceptx": sq(r["acceptx"]), "accepti": sq(r["accepti"]),
            "initial": init_arr, "final": sq(r["final"])}
     if not parallel:
         out["ibatch"] = sq(r["ibatch"])
+    if debug:      # slot order of temper.c:282-464
+        for key in ("which", "unif.which", "state", "log.hastings", "unif.hastings", "proposal", "acceptd",
+                    "norm", "unif.choose") + (("coproposal",) if parallel else ()):
+            out[key] = sq(r[key])
     return out
 
 

@@ -414,6 +414,9 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     }
     if (!o->batch || !o->acceptx || !o->accepti || !o->final || (!a->parallel && !o->ibatch))
         return set_error(MCMCHIP_EINVAL, "null output");
+    if (a->debug && (!o->which || !o->unif_which || !o->state || !o->log_hastings || !o->unif_hastings || !o->proposal ||
+                     !o->acceptd || !o->norm || !o->unif_choose || (a->parallel && !o->coproposal)))
+        return set_error(MCMCHIP_EINVAL, "debug requested but trace outputs are NULL");
 
     hipStream_t s = dc->stream;
     const int dp = a->device_ptrs;
@@ -432,6 +435,20 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     HIP_TRY(acceptx.set(o->acceptx, (size_t)nens * k * 8, dp));
     HIP_TRY(accepti.set(o->accepti, (size_t)nens * k * k * 8, dp));
     HIP_TRY(final_.set(o->final, (size_t)nens * nstate * 8, dp));
+    OutBuf dwhich, duw, dstate, dlh, duh, dprop, dacc, dnorm, duc, dcop;
+    if (a->debug) {
+        const size_t T = (size_t)nens * niter;
+        HIP_TRY(dwhich.set(o->which, T * 4, dp));
+        HIP_TRY(duw.set(o->unif_which, T * 8, dp));
+        HIP_TRY(dstate.set(o->state, T * nstate * 8, dp));
+        HIP_TRY(dlh.set(o->log_hastings, T * 8, dp));
+        HIP_TRY(duh.set(o->unif_hastings, T * 8, dp));
+        HIP_TRY(dprop.set(o->proposal, T * (p + 1) * 8, dp));
+        HIP_TRY(dacc.set(o->acceptd, T * 4, dp));
+        HIP_TRY(dnorm.set(o->norm, T * p * 8, dp));
+        HIP_TRY(duc.set(o->unif_choose, T * (a->parallel ? 2 : 1) * 8, dp));
+        if (a->parallel) HIP_TRY(dcop.set(o->coproposal, T * (p + 1) * 8, dp));
+    }
     HIP_TRY(hipMemsetAsync(dc->d_flag, 0, sizeof(int), s));
 
     TemperDev q;
@@ -444,6 +461,11 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     q.seed = a->seed; q.ens_offset = a->ens_offset; q.iter_offset = a->iter_offset;
     q.batch = batch.as<double>(); q.ibatch = ibatch.as<double>(); q.acceptx = acceptx.as<double>();
     q.accepti = accepti.as<double>(); q.final_ = final_.as<double>();
+    q.debug = a->debug;
+    q.dbg_which = dwhich.as<int>(); q.dbg_acceptd = dacc.as<int>(); q.dbg_unif_which = duw.as<double>();
+    q.dbg_state = dstate.as<double>(); q.dbg_lh = dlh.as<double>(); q.dbg_uh = duh.as<double>();
+    q.dbg_proposal = dprop.as<double>(); q.dbg_norm = dnorm.as<double>(); q.dbg_unif_choose = duc.as<double>();
+    q.dbg_coproposal = dcop.as<double>();
     q.flag = dc->d_flag;
     timing_reset("temper_kernel");
     timing_begin(s);
@@ -457,6 +479,12 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     HIP_TRY(acceptx.finish(s));
     HIP_TRY(accepti.finish(s));
     HIP_TRY(final_.finish(s));
+    if (a->debug) {
+        HIP_TRY(dwhich.finish(s)); HIP_TRY(duw.finish(s)); HIP_TRY(dstate.finish(s)); HIP_TRY(dlh.finish(s));
+        HIP_TRY(duh.finish(s)); HIP_TRY(dprop.finish(s)); HIP_TRY(dacc.finish(s)); HIP_TRY(dnorm.finish(s));
+        HIP_TRY(duc.finish(s));
+        if (a->parallel) HIP_TRY(dcop.finish(s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     o->iter_offset_out = a->iter_offset + (uint64_t)niter;
     return MCMCHIP_OK;

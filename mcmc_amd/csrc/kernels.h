@@ -56,6 +56,9 @@ struct TemperDev {
     const double *unif, *norm;
     unsigned long long seed, ens_offset, iter_offset;
     double *batch, *ibatch, *acceptx, *accepti, *final_;
+    int debug;
+    int *dbg_which, *dbg_acceptd;
+    double *dbg_unif_which, *dbg_state, *dbg_lh, *dbg_uh, *dbg_proposal, *dbg_norm, *dbg_unif_choose, *dbg_coproposal;
     int *flag;
 };
 int launch_temper(const TemperDev &p, hipStream_t s);

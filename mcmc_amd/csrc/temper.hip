@@ -127,6 +127,11 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     up = Ubuf + (it & 63) * 4;
                 }
                 u0 = up[0]; u1 = up[1];
+#define TDBG(arr, w, j) (arr)[(size_t)e * (w) * niter + it + (size_t)niter * (j)]
+                if (q.debug) {       // temper.c:528-543: state before the update, the within/swap draw
+                    for (int i = lane; i < nstate; i += 64) TDBG(q.dbg_state, nstate, i) = S[i];
+                    if (lane == 0) { q.dbg_which[(size_t)e * niter + it] = u0 < 0.5; q.dbg_unif_which[(size_t)e * niter + it] = u0; }
+                }
                 const bool within = u0 < 0.5;          // temper.c:537-538
                 double lh;
                 int ci, cj = 0;                        // 1-based components
@@ -155,6 +160,18 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     __syncthreads();
                     ly = lud_temper(q.kind, p, q.par, k, ci, Y);
                     lh = ly - L[ci - 1];
+                    if (q.debug) {   // temper.c:589-609 / 653-665
+                        for (int j = lane; j < p; j += 64) {
+                            TDBG(q.dbg_proposal, p + 1, j + 1) = Y[j];
+                            TDBG(q.dbg_norm, p, j) = Z[j];
+                            if (par) TDBG(q.dbg_coproposal, p + 1, j + 1) = S[(ci - 1) + k * j];
+                        }
+                        if (lane == 0) {
+                            TDBG(q.dbg_proposal, p + 1, 0) = ci;
+                            if (par) { TDBG(q.dbg_coproposal, p + 1, 0) = ci; TDBG(q.dbg_unif_choose, 2, 0) = u1; TDBG(q.dbg_unif_choose, 2, 1) = NAN; }
+                            else q.dbg_unif_choose[(size_t)e * niter + it] = NAN;
+                        }
+                    }
                     if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
                 } else if (par) {
                     u2 = up[2];
@@ -165,20 +182,46 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     sco = lud_temper(q.kind, p, q.par, k, cj, xi);   // (j, x_i) first (temper.c:738-739)
                     spr = lud_temper(q.kind, p, q.par, k, ci, xj);   // (i, x_j)
                     lh = spr + sco - L[cj - 1] - L[ci - 1];       // temper.c:742-744
+                    if (q.debug) {   // coproposal = (i, x_i), proposal = (j, x_j) (temper.c:720-731,757-766)
+                        for (int j = lane; j < p; j += 64) {
+                            TDBG(q.dbg_proposal, p + 1, j + 1) = xj[j];
+                            TDBG(q.dbg_coproposal, p + 1, j + 1) = xi[j];
+                            TDBG(q.dbg_norm, p, j) = NAN;
+                        }
+                        if (lane == 0) {
+                            TDBG(q.dbg_proposal, p + 1, 0) = cj;
+                            TDBG(q.dbg_coproposal, p + 1, 0) = ci;
+                            TDBG(q.dbg_unif_choose, 2, 0) = u1;
+                            TDBG(q.dbg_unif_choose, 2, 1) = u2;
+                        }
+                    }
                     if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (lane == 0) atomicOr(q.flag, FLAG_NAN); }
                 } else {
                     ci = (int)S[0];
                     cj = nb[(ci - 1) * maxnn + pick1(u1, nn[ci - 1]) - 1] + 1;
                     ly = lud_temper(q.kind, p, q.par, k, cj, S + 1);
                     lh = ly - L[ci - 1] + log((double)nn[ci - 1]) - log((double)nn[cj - 1]);   // temper.c:810-812
+                    if (q.debug) {   // temper.c:825-835
+                        for (int j = lane; j < p; j += 64) { TDBG(q.dbg_proposal, p + 1, j + 1) = S[1 + j]; TDBG(q.dbg_norm, p, j) = NAN; }
+                        if (lane == 0) { TDBG(q.dbg_proposal, p + 1, 0) = cj; q.dbg_unif_choose[(size_t)e * niter + it] = u1; }
+                    }
                     if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
                 }
                 if (isnan(lh) || (isinf(lh) && lh > 0)) { if (lane == 0) atomicOr(q.flag, FLAG_HASTINGS); lh = -INFINITY; }
+                const double lh_trace = lh;
                 bool accept = true;
+                double uh_trace = NAN;
                 if (lh < 0.0) {                                   // temper.c:582-587
                     u3 = up[3];
+                    uh_trace = u3;
                     accept = u3 < exp(lh);
                 }
+                if (q.debug && lane == 0) {
+                    q.dbg_lh[(size_t)e * niter + it] = lh_trace;
+                    q.dbg_uh[(size_t)e * niter + it] = uh_trace;
+                    q.dbg_acceptd[(size_t)e * niter + it] = accept;
+                }
+#undef TDBG
                 __syncthreads();   // every lane has read S / L / Y for this decision
                 if (within) {
                     if (accept) {

@@ -148,7 +148,7 @@ def metrop(target, initial, nbatch, blen=1, nspac=1, scale=1.0, outfun=None, deb
 
 def temper(target, initial, neighbors, nbatch, blen=1, nspac=1, scale=1.0, parallel=False,
            rstream=None, unif=None, norm=None, seed=None, ens_offset=0, iter_offset=0,
-           out_kind=TOUT_NONE, nthreads=1):
+           out_kind=TOUT_NONE, nthreads=1, debug=False):
     if rstream is not None:
         mode = RNG_RSTREAM
     elif unif is not None:
@@ -159,7 +159,7 @@ def temper(target, initial, neighbors, nbatch, blen=1, nspac=1, scale=1.0, paral
     nout = {TOUT_NONE: None, TOUT_WITCH_PAR: k, TOUT_WITCH_SER: 2 * k}[out_kind]
     call = abi.TemperCall(target.d, initial, neighbors, nbatch, blen, nspac, scale, parallel,
                           rng_mode=abi.RNG_PHILOX, unif=unif, norm=norm, seed=seed or 0,
-                          ens_offset=ens_offset, iter_offset=iter_offset, nout=nout)
+                          ens_offset=ens_offset, iter_offset=iter_offset, nout=nout, debug=debug)
     call.args.rng_mode = mode
     err = C.create_string_buffer(256)
     rc = lib().orc_temper(C.addressof(target.desc), C.addressof(call.args), C.addressof(call.out),

@@ -553,12 +553,20 @@ static int temper_ens(const mcmchip_target_desc *t, const mcmchip_temper_args *a
         for (int i = 0; i < k; i++) ibuf[i] = 0.0;
         for (int jb = 0; jb < a->blen; jb++) {
             for (int is = 0; is < a->nspac; is++, it++) {
+                /* debug trace (temper.c:528-543): state before the update */
+                const int dbg = a->debug && o->which;
+                const size_t eb = (size_t)e * niter + it;      /* scalar traces */
+#define DBG2(arr, w, j) (arr)[(size_t)e * (w) * niter + it + (size_t)niter * (j)]
+                if (dbg) for (int q = 0; q < nstate; q++) DBG2(o->state, nstate, q) = state[q];
                 double uw = t_unif(&dr, it, SLOT_WHICH);
                 int within = uw < 0.5;
                 double lh;
                 int accept = 1;
+                double uh = NAN, uc1 = NAN, uc2 = NAN;
+                if (dbg) { o->which[eb] = within; o->unif_which[eb] = uw; }
                 if (within) {
-                    int i = par ? pick(t_unif(&dr, it, SLOT_CHOOSE1), k) : (int)state[0];
+                    if (par) uc1 = t_unif(&dr, it, SLOT_CHOOSE1);
+                    int i = par ? pick(uc1, k) : (int)state[0];
                     if (par) for (int j = 0; j < p; j++) xi[j] = state[(i - 1) + k * j];
                     else for (int j = 0; j < p; j++) xi[j] = state[1 + j];
                     t_norm(&dr, it, z);
@@ -567,7 +575,15 @@ static int temper_ens(const mcmchip_target_desc *t, const mcmchip_temper_args *a
                     if (ly == INFINITY || isnan(ly)) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density function returned NA or NaN");
                     lh = ly - L[i - 1];
                     if (isnan(lh) || (isinf(lh) && lh > 0)) return fail(err, errlen, MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
-                    if (lh < 0.0) accept = t_unif(&dr, it, SLOT_HAST) < exp(lh);
+                    if (lh < 0.0) { uh = t_unif(&dr, it, SLOT_HAST); accept = uh < exp(lh); }
+                    if (dbg) {
+                        DBG2(o->proposal, p + 1, 0) = i;
+                        for (int j = 0; j < p; j++) { DBG2(o->proposal, p + 1, j + 1) = y[j]; DBG2(o->norm, p, j) = z[j]; }
+                        if (par) {
+                            DBG2(o->coproposal, p + 1, 0) = i;
+                            for (int j = 0; j < p; j++) DBG2(o->coproposal, p + 1, j + 1) = xi[j];
+                        }
+                    }
                     if (accept) {
                         if (par) for (int j = 0; j < p; j++) state[(i - 1) + k * j] = y[j];
                         else for (int j = 0; j < p; j++) state[1 + j] = y[j];
@@ -576,8 +592,10 @@ static int temper_ens(const mcmchip_target_desc *t, const mcmchip_temper_args *a
                     }
                     ax_d[i - 1]++;
                 } else if (par) {
-                    int i = pick(t_unif(&dr, it, SLOT_CHOOSE1), k);
+                    uc1 = t_unif(&dr, it, SLOT_CHOOSE1);
+                    int i = pick(uc1, k);
                     double u2 = t_unif(&dr, it, SLOT_CHOOSE2);
+                    uc2 = u2;
                     int jj = nb[i - 1][pick(u2, nn[i - 1]) - 1] + 1;
                     for (int j = 0; j < p; j++) { xi[j] = state[(i - 1) + k * j]; xj[j] = state[(jj - 1) + k * j]; }
                     double sco = orc_lud_temper(t, jj, xi); /* (j, x_i) first (temper.c:738-739) */
@@ -586,7 +604,16 @@ static int temper_ens(const mcmchip_target_desc *t, const mcmchip_temper_args *a
                         return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density function returned NA or NaN");
                     lh = spr + sco - L[jj - 1] - L[i - 1];   /* temper.c:742-744 */
                     if (isnan(lh) || (isinf(lh) && lh > 0)) return fail(err, errlen, MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
-                    if (lh < 0.0) accept = t_unif(&dr, it, SLOT_HAST) < exp(lh);
+                    if (lh < 0.0) { uh = t_unif(&dr, it, SLOT_HAST); accept = uh < exp(lh); }
+                    if (dbg) {   /* coproposal = (i, x_i), proposal = (j, x_j) (temper.c:720-731) */
+                        DBG2(o->proposal, p + 1, 0) = jj;
+                        DBG2(o->coproposal, p + 1, 0) = i;
+                        for (int j = 0; j < p; j++) {
+                            DBG2(o->proposal, p + 1, j + 1) = xj[j];
+                            DBG2(o->coproposal, p + 1, j + 1) = xi[j];
+                            DBG2(o->norm, p, j) = NAN;
+                        }
+                    }
                     if (accept) {
                         for (int j = 0; j < p; j++) { state[(jj - 1) + k * j] = xi[j]; state[(i - 1) + k * j] = xj[j]; }
                         L[i - 1] = spr;
@@ -596,12 +623,17 @@ static int temper_ens(const mcmchip_target_desc *t, const mcmchip_temper_args *a
                     ai_d[i - 1][jj - 1]++;
                 } else {
                     int i = (int)state[0];
-                    int jj = nb[i - 1][pick(t_unif(&dr, it, SLOT_CHOOSE1), nn[i - 1]) - 1] + 1;
+                    uc1 = t_unif(&dr, it, SLOT_CHOOSE1);
+                    int jj = nb[i - 1][pick(uc1, nn[i - 1]) - 1] + 1;
                     double ly = orc_lud_temper(t, jj, state + 1);
                     if (ly == INFINITY || isnan(ly)) return fail(err, errlen, MCMCHIP_EDOMAIN, "log unnormalized density function returned NA or NaN");
                     lh = ly - L[i - 1] + log((double)nn[i - 1]) - log((double)nn[jj - 1]); /* temper.c:810-812 */
                     if (isnan(lh) || (isinf(lh) && lh > 0)) return fail(err, errlen, MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
-                    if (lh < 0.0) accept = t_unif(&dr, it, SLOT_HAST) < exp(lh);
+                    if (lh < 0.0) { uh = t_unif(&dr, it, SLOT_HAST); accept = uh < exp(lh); }
+                    if (dbg) {
+                        DBG2(o->proposal, p + 1, 0) = jj;
+                        for (int j = 0; j < p; j++) { DBG2(o->proposal, p + 1, j + 1) = state[1 + j]; DBG2(o->norm, p, j) = NAN; }
+                    }
                     if (accept) {
                         state[0] = jj;
                         L[jj - 1] = ly;
@@ -609,6 +641,14 @@ static int temper_ens(const mcmchip_target_desc *t, const mcmchip_temper_args *a
                     }
                     ai_d[i - 1][jj - 1]++;
                 }
+                if (dbg) {
+                    o->log_hastings[eb] = lh;
+                    o->unif_hastings[eb] = uh;
+                    o->acceptd[eb] = accept;
+                    if (par) { DBG2(o->unif_choose, 2, 0) = uc1; DBG2(o->unif_choose, 2, 1) = uc2; }
+                    else o->unif_choose[eb] = uc1;
+                }
+#undef DBG2
             }
             t_out(t, a, out_kind, state, g);
             for (int i = 0; i < nout; i++) buf[i] += g[i];

@@ -432,3 +432,122 @@ def test_olbm_vs_oracle(api, oracle_mod, n, p, blen):
     assert np.max(np.abs(got2 - ref)) <= tol
     with pytest.raises(ValueError, match="batch.length must be <= nrow"):
         api.olbm(x, n + 1)
+
+
+# ----------------------------------------------------------------------------- temper debug trace
+def _lud_witch(par, p, comp, theta):
+    if np.any(np.abs(theta) > 1.0):
+        return -np.inf
+    bnd = par[int(comp) - 1]
+    if np.all(np.abs(theta) > bnd):
+        return -(p + 1) * np.log(2) - p * np.log(1 - bnd)
+    return -(p + 1) * np.log(2) - np.log1p(-(1 - bnd) ** p)
+
+
+@pytest.mark.parametrize("parallel", [True, False])
+def test_temper_debug_trace_checks(api, oracle_mod, parallel):
+    """The 14 checks of vignettes/debug.Rnw:250-267 as run by tests/temp-par.R:68-218 and
+    tests/temp-ser.R:53-291, on the DEVICE trace, plus bitwise equality with the oracle's trace."""
+    k, p, E = 6, 3, 8
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    i, j = np.indices((k, k))
+    nb = (np.abs(i - j) == 1) | (np.abs(i - j) == 2)
+    nbatch, blen, nspac, scale = 20, 10, 5, 0.3456789
+    niter = nbatch * blen * nspac
+    rng = np.random.default_rng(77)
+    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+    init = np.zeros((E, k, p)) if parallel else np.column_stack([np.ones(E), np.zeros((E, p))])
+    o = api.temper(api.Target(abi.T_WITCH, p, par=par), init, nb, nbatch, blen, nspac, scale, parallel=parallel,
+                   unif=unif, norm=norm, debug=True)
+    ref = oracle_mod.temper(oracle_mod.Target(abi.T_WITCH, p, par=par), init, nb, nbatch, blen, nspac, scale,
+                            parallel=parallel, unif=unif, norm=norm, debug=True)
+    keys = ["which", "unif.which", "state", "log.hastings", "unif.hastings", "proposal", "acceptd", "norm",
+            "unif.choose"] + (["coproposal"] if parallel else [])
+    for key in keys:
+        assert np.array_equal(o[key], ref[key], equal_nan=True), key
+    assert list(o.keys())[-len(keys):] == keys                       # slot order of temper.c:282-464
+    nn = nb.sum(axis=1)
+    for e in range(E):
+        which, prop = o["which"][e], o["proposal"][e]
+        lh, uh, acc = o["log.hastings"][e], o["unif.hastings"][e], o["acceptd"][e]
+        state, nrm, uc = o["state"][e], o["norm"][e], o["unif.choose"][e]
+        # 1. decision about within-component or jump/swap
+        assert np.array_equal(o["unif.which"][e] < 0.5, which)
+        # 5./6. hastings rejection decided correctly
+        assert np.array_equal(lh >= 0, np.isnan(uh))
+        assert np.all((lh < 0) | acc)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(acc, (lh >= 0) | (uh < np.exp(lh)))
+        # the uniforms/normals are the injected ones, consumed in the reference's order (temp-par.R:164-187)
+        assert np.array_equal(o["unif.which"][e], unif[e, :, 0])
+        assert np.array_equal(nrm[which], norm[e][which]) and np.all(np.isnan(nrm[~which]))
+        assert np.array_equal(uh[lh < 0], unif[e, lh < 0, 3])
+        after = np.concatenate([state[1:], o["final"][e][None]], axis=0)
+        if parallel:
+            cop = o["coproposal"][e]
+            pi, ci = prop[:, 0].astype(int), cop[:, 0].astype(int)
+            assert np.array_equal(which, pi == ci)                                   # 2.
+            for t in range(niter):                                                   # 3. provenance
+                assert np.array_equal(cop[t, 1:], state[t, ci[t] - 1])
+                if not which[t]:
+                    assert np.array_equal(prop[t, 1:], state[t, pi[t] - 1])
+            # 4. hastings ratio
+            f = np.array([_lud_witch(par, p, prop[t, 0], prop[t, 1:]) for t in range(niter)])
+            fc = np.array([_lud_witch(par, p, cop[t, 0], cop[t, 1:]) for t in range(niter)])
+            fs = np.array([_lud_witch(par, p, cop[t, 0], prop[t, 1:]) for t in range(niter)])
+            fcs = np.array([_lud_witch(par, p, prop[t, 0], cop[t, 1:]) for t in range(niter)])
+            with np.errstate(invalid="ignore"):
+                want = np.where(which, f - fc, fs + fcs - f - fc)
+            assert np.allclose(want, lh, rtol=1e-13, atol=1e-13)
+            # 7. acceptance carried out
+            mine = state.copy()
+            for t in range(niter):
+                if acc[t]:
+                    if which[t]:
+                        mine[t, pi[t] - 1] = prop[t, 1:]
+                    else:
+                        mine[t, pi[t] - 1] = cop[t, 1:]
+                        mine[t, ci[t] - 1] = prop[t, 1:]
+            assert np.array_equal(after, mine)
+            # 8./9. within-component proposal and component choice
+            assert np.max(np.abs(prop[which, 1:] - (cop[which, 1:] + scale * nrm[which]))) < 1e-15
+            assert np.array_equal(np.floor(k * uc[which, 0]) + 1, cop[which, 0]) and np.all(np.isnan(uc[which, 1]))
+            # 10. swap partner selection
+            mi = (np.floor(k * uc[~which, 0]) + 1).astype(int)
+            mk = (np.floor(nn[mi - 1] * uc[~which, 1]) + 1).astype(int)
+            mj = np.array([np.nonzero(nb[a - 1])[0][b - 1] + 1 for a, b in zip(mi, mk)])
+            assert np.array_equal(cop[~which, 0], mi) and np.array_equal(prop[~which, 0], mj)
+            assert np.array_equal(uc[:, 0], unif[e, :, 1]) and np.array_equal(uc[~which, 1], unif[e, ~which, 2])
+            # 12. batch means
+            kept = after[nspac - 1::nspac].reshape(nbatch, blen, k, p).mean(axis=1)
+            assert np.allclose(kept, o["batch"][e], rtol=1e-14, atol=1e-15)
+            # 13./14. acceptance rates
+            ax = np.array([acc[which & (ci == c + 1)].mean() if np.any(which & (ci == c + 1)) else np.nan
+                           for c in range(k)])
+            assert np.array_equal(ax, o["acceptx"][e], equal_nan=True)
+            ai = np.full((k, k), np.nan)
+            for a in range(k):
+                for b in range(k):
+                    sel = ~which & (ci == a + 1) & (pi == b + 1)
+                    if nb[a, b] and np.any(sel):
+                        ai[a, b] = acc[sel].mean()
+            assert np.array_equal(ai, o["accepti"][e], equal_nan=True)
+        else:
+            si, pi = state[:, 0].astype(int), prop[:, 0].astype(int)
+            assert np.array_equal(which, pi == si)                                   # temp-ser.R
+            f = np.array([_lud_witch(par, p, state[t, 0], state[t, 1:]) for t in range(niter)])
+            g = np.array([_lud_witch(par, p, prop[t, 0], prop[t, 1:]) for t in range(niter)])
+            with np.errstate(invalid="ignore"):
+                want = g - f - np.log(nn[pi - 1]) + np.log(nn[si - 1])               # temp-ser-witch.R:95-101
+            assert np.allclose(want, lh, rtol=1e-13, atol=1e-13)
+            mine = np.where(acc[:, None], prop, state)
+            assert np.array_equal(after, mine)
+            assert np.max(np.abs(prop[which, 1:] - (state[which, 1:] + scale * nrm[which]))) < 1e-15
+            assert np.all(np.isnan(uc[which])) and np.array_equal(uc[~which], unif[e, ~which, 1])
+            mk = (np.floor(nn[si[~which] - 1] * uc[~which]) + 1).astype(int)
+            mj = np.array([np.nonzero(nb[a - 1])[0][b - 1] + 1 for a, b in zip(si[~which], mk)])
+            assert np.array_equal(prop[~which, 0], mj)
+            kept = after[nspac - 1::nspac]
+            assert np.allclose(kept[:, 1:].reshape(nbatch, blen, p).mean(axis=1), o["batch"][e], rtol=1e-14, atol=1e-15)
+            ib = np.stack([(kept[:, 0] == c + 1).reshape(nbatch, blen).mean(axis=1) for c in range(k)], axis=1)
+            assert np.array_equal(ib, o["ibatch"][e])                                # temp-ser.R:152-161
