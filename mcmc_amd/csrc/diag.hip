@@ -15,7 +15,8 @@
 //   Window sums are rebuilt per 64-window slab from a wave prefix scan of x[t+len]-x[t]
 //   (coalesced along time because x is column-major), seeded per time segment by a direct
 //   centred sum, so rounding does not accumulate along n as in the reference's running
-//   recurrence (olbm.c:61-62).  Each workgroup owns one 16 x 16 tile pair of the lower triangle.
+//   recurrence (olbm.c:61-62).  Each workgroup owns one 64 x 64 tile pair of the lower triangle,
+//   4 x 4 outputs per lane in registers (fp64 MFMA has no rate advantage over fp64 FMA on gfx950).
 #include "kernels.h"
 #include <math.h>
 #include <vector>
@@ -207,8 +208,9 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
 // =============================================================================================
 // olbm
 // =============================================================================================
-#define OL_SLAB 64          // windows per slab
-#define OL_SEG_SLABS 256    // slabs per time segment (16384 windows)
+#define OL_SLAB 64          // windows per slab (one wave-wide prefix scan)
+#define OL_CT 64            // columns per tile: a workgroup owns a 64 x 64 tile pair of var
+#define OL_LD 129           // LDS row stride in doubles (odd-ish: conflict-free column writes)
 
 __global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ x, long n, long chunk, long nchunk,
                                                      double *__restrict__ partial)
@@ -235,88 +237,375 @@ __global__ void colmean_kernel(const double *__restrict__ partial, long nchunk, 
     mean[col] = s / (double)n;     // olbm.c:42
 }
 
-// one workgroup = one time segment x one 16x16 tile pair (ti >= tj) of var
+// one workgroup = one time segment x one 64 x 64 tile pair (ti >= tj) of var.
+// Phase 1 (per 64-window slab): each wave rebuilds the centred window sums of 32 of the 128 columns with a
+//   wave prefix scan over x[t+len] - x[t] (lanes = consecutive windows: coalesced 512-B loads) -> LDS.
+// Phase 2: every thread holds a 4 x 4 block of the 64 x 64 output in registers and walks the 64 windows
+//   (8 broadcast-friendly ds_read_b64 per 16 FMAs).
 __global__ __launch_bounds__(256) void olbm_kernel(const double *__restrict__ x, long n, int p, long len, long nwin,
-                                                   const double *__restrict__ mean, int npairs,
+                                                   long seg_windows, const double *__restrict__ mean, int npairs,
                                                    double *__restrict__ partial)
 {
-    __shared__ double W[OL_SLAB][33];   // centred window sums: [window][0..15 = I cols, 16..31 = J cols]
+    __shared__ double W[OL_SLAB * OL_LD];   // [window][0..63 = I cols, 64..127 = J cols]
+    __shared__ double base[2 * OL_CT];      // centred sum of the window that starts the current slab
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    // decode the tile pair
     int pair = blockIdx.y, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= pair) ti++;
     const int tj = pair - ti * (ti + 1) / 2;
-    const long w_begin = (long)blockIdx.x * OL_SLAB * OL_SEG_SLABS;
-    long w_end = w_begin + (long)OL_SLAB * OL_SEG_SLABS;
+    const long w_begin = (long)blockIdx.x * seg_windows;
+    long w_end = w_begin + seg_windows;
     if (w_end > nwin) w_end = nwin;
 
-    // each wave owns 8 of the 32 columns; base[c] = centred sum of the window starting at w (wave-uniform)
-    double base[8];
-    int colv[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int lc = wave * 8 + c;
-        const int col = (lc < 16) ? ti * 16 + lc : tj * 16 + (lc - 16);
-        colv[c] = col < p ? col : -1;
+    // seed: direct centred sum of the first window of the segment, 32 columns per wave
+    for (int c = 0; c < 32; c++) {
+        const int lc = wave * 32 + c;
+        const int col = (lc < OL_CT) ? ti * OL_CT + lc : tj * OL_CT + (lc - OL_CT);
         double s = 0.0;
-        if (colv[c] >= 0) {
+        if (col < p) {
             const double *xc = x + (size_t)col * n;
             const double m = mean[col];
             for (long q = lane; q < len; q += 64) s += xc[w_begin + q] - m;
         }
         for (int mm = 32; mm > 0; mm >>= 1) s += __shfl_xor(s, mm, 64);
-        base[c] = s;
+        if (lane == 0) base[lc] = s;
     }
-    const int i = t & 15, j = t >> 4;    // output element (row i of tile ti, col j of tile tj)
-    double acc = 0.0;
-    for (long w0 = w_begin; w0 < w_end; w0 += OL_SLAB) {
+    __syncthreads();
+
+    const int a = t & 15, b = t >> 4;     // rows {a + 16m} of tile ti, cols {b + 16m'} of tile tj
+    double acc[4][4];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+
+    // x[w+len] - x[w] of the slab's 64 windows for this wave's 32 columns: all 64 loads are issued
+    // together (and the next slab's are issued before phase 2), so HBM latency is paid once per slab
+    const double *xcol[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) {
+        const int lc = wave * 32 + c;
+        const int col = (lc < OL_CT) ? ti * OL_CT + lc : tj * OL_CT + (lc - OL_CT);
+        xcol[c] = col < p ? x + (size_t)col * n : nullptr;
+    }
+    double dl[32];
+    auto load_slab = [&](long w0) {
+        const long w = w0 + lane;
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            double v = 0.0;
+            if (xcol[c] && w + len < n) v = xcol[c][w + len] - xcol[c][w];
+            dl[c] = v;
+        }
+    };
+    load_slab(w_begin);
+
+    for (long w0 = w_begin; w0 < w_end; w0 += OL_SLAB) {
+        const long w = w0 + lane;
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            const int lc = wave * 32 + c;
             // W[w0 + lane] = base + sum_{s < lane} (x[w0+s+len] - x[w0+s])   (olbm.c:61-62 as a prefix scan)
-            double dlt = 0.0;
-            const long w = w0 + lane;
-            if (colv[c] >= 0 && w + len < n) {
-                const double *xc = x + (size_t)colv[c] * n;
-                dlt = xc[w + len] - xc[w];
-            }
+            const double dlt = dl[c];
             double inc = dlt;    // inclusive scan
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const double up = __shfl_up(inc, off, 64);
                 if (lane >= off) inc += up;
             }
-            const double mine = base[c] + (inc - dlt);
-            W[lane][wave * 8 + c] = (w < w_end) ? mine : 0.0;
-            base[c] += __shfl(inc, 63, 64);
+            const double b0 = base[lc];
+            W[lane * OL_LD + lc] = (w < w_end) ? b0 + (inc - dlt) : 0.0;
+            if (lane == 63) base[lc] = b0 + inc;
+        }
+        if (w0 + OL_SLAB < w_end) load_slab(w0 + OL_SLAB);
+        __syncthreads();
+#pragma unroll 4
+        for (int s2 = 0; s2 < OL_SLAB; s2++) {
+            const double *row = W + s2 * OL_LD;
+            double wi[4], wj[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) { wi[m] = row[a + 16 * m]; wj[m] = row[OL_CT + b + 16 * m]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = fma(wi[i], wj[j], acc[i][j]);
         }
         __syncthreads();
-#pragma unroll 16
-        for (int s2 = 0; s2 < OL_SLAB; s2++) acc = fma(W[s2][i], W[s2][16 + j], acc);
-        __syncthreads();
     }
-    partial[((size_t)blockIdx.x * npairs + pair) * 256 + t] = acc;
+    double *out = partial + ((size_t)blockIdx.x * npairs + pair) * (OL_CT * OL_CT);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[(a + 16 * i) * OL_CT + (b + 16 * j)] = acc[i][j];
 }
 
 __global__ void olbm_finish_kernel(const double *__restrict__ partial, long nseg, int npairs, int p, double denom,
                                    double *__restrict__ var)
 {
-    const int pair = blockIdx.x, t = threadIdx.x;
+    const int pair = blockIdx.x;
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= pair) ti++;
     const int tj = pair - ti * (ti + 1) / 2;
-    double s = 0.0;
-    for (long g = 0; g < nseg; g++) s += partial[((size_t)g * npairs + pair) * 256 + t];
-    const int r = ti * 16 + (t & 15), c = tj * 16 + (t >> 4);
-    if (r < p && c < p) {
-        const double v = s / denom;          // olbm.c:74
-        var[r + (size_t)p * c] = v;
-        var[c + (size_t)p * r] = v;          // olbm.c:75 (symmetric)
+    for (int e = threadIdx.x; e < OL_CT * OL_CT; e += blockDim.x) {
+        double s = 0.0;
+        for (long g = 0; g < nseg; g++) s += partial[((size_t)g * npairs + pair) * (OL_CT * OL_CT) + e];
+        const int r = ti * OL_CT + e / OL_CT, c = tj * OL_CT + e % OL_CT;
+        if (r < p && c < p) {
+            const double v = s / denom;          // olbm.c:74
+            var[r + (size_t)p * c] = v;
+            var[c + (size_t)p * r] = v;          // olbm.c:75 (symmetric)
+        }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// p <= 256: all columns in one workgroup, outer products on the fp64 matrix cores.
+// var = V^T V with V[w][c] = (window sum of column c starting at w) - len*mean[c]: a GEMM whose K axis
+// is the window index.  One workgroup (8 waves) walks a segment of windows in 32-window slabs:
+//   load   lanes = consecutive windows: coalesced 256-B runs of x[t+len] - x[t]  -> LDS D[window][col]
+//   scan   one thread per column turns D into the centred window sums in place (olbm.c:61-62 recurrence,
+//          so the rounding is the reference's within a segment)
+//   mfma   v_mfma_f64_16x16x4 on 16-column fragments V[4 windows][16 cols].
+// The next slab's global loads are in flight during scan + mfma.
+//
+// Tile schedule.  With F fragments (F*16 >= p columns) var has F(F+1)/2 distinct 16 x 16 tiles; a tile is
+// an unordered fragment pair, so they are taken as the circulant family {f, (f+delta) mod F},
+// delta = 0..F/2: wave w owns NB = F/8 consecutive base fragments f and all their delta < F/2 tiles, and
+// the delta = F/2 pairs (each shared by two bases) are split so every wave gets at most one.  At F = 16
+// that is exactly 17 tiles on each of the 8 waves.  The columns of the first F/2+1 fragments are stored
+// a second time after column 16F, so (f+delta) never wraps: every fragment a wave needs in a k-step sits
+// at (one base register) + (compile-time offset) and a k-step costs NB + F/2 ds_read_b64 for its MFMAs.
+#define OM_SLAB 32
+#define OM_NW 8
+
+typedef double om_double4 __attribute__((ext_vector_type(4)));
+
+template <int F> struct OmShape {
+    static constexpr int NB = F >= 8 ? F / 8 : 1;       // base fragments per wave
+    static constexpr int NACT = F / NB;                 // waves that own tiles (8, or 4 at F = 4)
+    static constexpr int H = F / 2;
+    static constexpr int NS = NB * H + 1;               // accumulator tiles per wave (last = the delta = H tile)
+    static constexpr int NFR = NB + H;                  // fragments read per k-step
+    static constexpr int PP = F * 16;
+    static constexpr int LD = PP + (H + 1) * 16 + 1;    // odd: conflict-free transposed writes and fragment reads
+    static constexpr int NLD = PP / (2 * OM_NW);        // columns each thread loads per slab
+    // the delta = H tile of wave w: base index and whether the wave has one
+    __host__ __device__ static constexpr int extra_base(int w) { return NB == 2 ? (w < NACT / 2 ? 0 : 1) : 0; }
+    __host__ __device__ static constexpr bool has_extra(int w) { return NB == 2 ? true : w < NACT / 2; }
+    static constexpr size_t lds_bytes = ((size_t)OM_SLAB * LD + PP) * 8;
+};
+
+template <int F>
+__global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__restrict__ x, long n, int p, long len,
+                                                               long nwin, long seg_windows,
+                                                               const double *__restrict__ mean,
+                                                               double *__restrict__ partial)
+{
+    using S = OmShape<F>;
+    constexpr int LD = S::LD, PP = S::PP, H = S::H, NB = S::NB;
+    extern __shared__ double om_sm[];
+    double *V = om_sm;                       // [OM_SLAB][LD]
+    double *run = om_sm + OM_SLAB * LD;      // [PP] centred sum of the window that starts the next slab
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const long w_begin = (long)blockIdx.x * seg_windows;
+    long w_end = w_begin + seg_windows;
+    if (w_end > nwin) w_end = nwin;
+
+    // seed: direct centred sum of the segment's first window (olbm.c:52-57 restarted per segment);
+    // four columns per wave in flight, lanes strided over the window
+    for (int c0 = wave; c0 < PP; c0 += 4 * OM_NW) {
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (c0 < p) {
+            const double *xc[4];
+            double m4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int c = c0 + u * OM_NW < p ? c0 + u * OM_NW : c0;     // clamp: the duplicate is dropped below
+                xc[u] = x + (size_t)c * n + w_begin;
+                m4[u] = mean[c];
+            }
+#pragma unroll 4
+            for (long q = lane; q < len; q += 64)
+#pragma unroll
+                for (int u = 0; u < 4; u++) s4[u] += xc[u][q] - m4[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double sv = s4[u];
+            for (int mm = 32; mm > 0; mm >>= 1) sv += __shfl_xor(sv, mm, 64);
+            const int c = c0 + u * OM_NW;
+            if (lane == 0 && c < PP) run[c] = c < p ? sv : 0.0;
+        }
+    }
+
+    om_double4 acc[S::NS];
+#pragma unroll
+    for (int q = 0; q < S::NS; q++) acc[q] = om_double4{0.0, 0.0, 0.0, 0.0};
+    // the K index of the GEMM is a dummy: lane group g = lane/16 of k-step ks takes window row
+    // 2*ks + g/2 + 16*(g%2), so the two groups that share a 32-lane LDS access are 16 rows apart
+    // = 32 banks apart with an odd LD: ds_read_b64 is conflict-free (bank = (addr/4) % 64).
+    const int g = lane >> 4;
+    const double *Vw = V + ((g >> 1) + 16 * (g & 1)) * LD + (lane & 15) + 16 * NB * wave;
+    const bool mfma_wave = wave < S::NACT;
+    const bool extra_on_b1 = S::extra_base(wave) == 1, extra = S::has_extra(wave);
+
+    // load phase: lanes 0-31 / 32-63 = 32 consecutive windows of two adjacent columns.
+    // address = (wave-uniform 64-bit base) + (32-bit lane offset): no per-column pointer registers
+    const int sub = lane >> 5, wl = lane & 31;
+    const unsigned lane_lo = (unsigned)((size_t)sub * n + wl), lane_hi = lane_lo + (unsigned)len;
+    // the raw loads stay in registers (not their difference) so that nothing waits on them until the
+    // next slab's D write: their HBM latency hides behind the scan and mfma phases
+    double hi[S::NLD], lo[S::NLD];
+    auto load_slab = [&](long w0) {
+        const bool ok = w0 + wl + len < n;
+#pragma unroll
+        for (int q = 0; q < S::NLD; q++) {
+            const int c = q * 2 * OM_NW + wave * 2 + sub;
+            const double *xq = x + (size_t)(q * 2 * OM_NW + wave * 2) * n + w0;      // uniform
+            hi[q] = 0.0;
+            lo[q] = 0.0;
+            if (c < p && ok) {
+                hi[q] = xq[lane_hi];
+                lo[q] = xq[lane_lo];
+            }
+        }
+    };
+    load_slab(w_begin);
+
+#ifdef OM_PROF
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter(), tn;
+#define OM_TICK(i) { tn = __builtin_readcyclecounter(); tp[i] += tn - tc; tc = tn; }
+#else
+#define OM_TICK(i)
+#endif
+    for (long w0 = w_begin; w0 < w_end; w0 += OM_SLAB) {
+        __syncthreads();                     // previous slab's fragments are consumed; run[] is written
+        OM_TICK(0)
+#pragma unroll
+        for (int q = 0; q < S::NLD; q++) V[wl * LD + q * 2 * OM_NW + wave * 2 + sub] = hi[q] - lo[q];
+        if (w0 + OM_SLAB < w_end) load_slab(w0 + OM_SLAB);
+        OM_TICK(1)
+        __syncthreads();
+        OM_TICK(2)
+        if (tid < PP) {
+            double r = run[tid];
+            const bool dup = tid < (H + 1) * 16;
+#pragma unroll 8
+            for (int s2 = 0; s2 < OM_SLAB; s2++) {
+                const double d = V[s2 * LD + tid];
+                const double v = (w0 + s2 < w_end) ? r : 0.0;
+                V[s2 * LD + tid] = v;
+                if (dup) V[s2 * LD + PP + tid] = v;
+                r += d;
+            }
+            run[tid] = r;
+        }
+        OM_TICK(3)
+        __syncthreads();
+        OM_TICK(4)
+        if (mfma_wave) {
+#pragma unroll 2
+            for (int ks = 0; ks < OM_SLAB / 4; ks++) {
+                const double *Vk = Vw + 2 * ks * LD;
+                double fr[S::NFR];
+#pragma unroll
+                for (int i = 0; i < S::NFR; i++) fr[i] = Vk[16 * i];
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int dlt = 0; dlt < H; dlt++)
+                        acc[b * H + dlt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[b], fr[b + dlt], acc[b * H + dlt], 0, 0, 0);
+                if constexpr (NB == 2) {     // every wave has one: operands picked by a wave-uniform select
+                    const double ea = extra_on_b1 ? fr[1] : fr[0], eb = extra_on_b1 ? fr[1 + H] : fr[H];
+                    acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea, eb, acc[NB * H], 0, 0, 0);
+                } else if (extra) {
+                    acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[0], fr[H], acc[NB * H], 0, 0, 0);
+                }
+            }
+        }
+        OM_TICK(5)
+    }
+#ifdef OM_PROF
+    if (blockIdx.x == 3 && lane == 0 && (wave == 0 || wave == 7))
+        printf("wave %d: topbarrier %llu dwrite %llu bar2 %llu scan %llu bar3 %llu mfma %llu\n", wave, tp[0], tp[1], tp[2],
+               tp[3], tp[4], tp[5]);
+#endif
+    // partial[segment][wave][slot][reg][lane]
+    if (mfma_wave) {
+        double *out = partial + ((size_t)blockIdx.x * S::NACT + wave) * S::NS * 256;
+#pragma unroll
+        for (int q = 0; q < S::NS; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[q * 256 + r * 64 + lane] = acc[q][r];
+    }
+}
+
+// one workgroup per (wave, slot) tile: sums the segments in order, scales (olbm.c:74) and mirrors (olbm.c:75).
+// accumulator layout of v_mfma_f64_16x16x4: register r of lane l holds D[row = l/16 + 4r][col = l % 16]
+template <int F>
+__global__ __launch_bounds__(256) void olbm_mfma_finish_kernel(const double *__restrict__ partial, long nseg, int p,
+                                                               double denom, double *__restrict__ var)
+{
+    using S = OmShape<F>;
+    const int w = blockIdx.x / S::NS, q = blockIdx.x % S::NS, e = threadIdx.x, r = e >> 6, l = e & 63;
+    int b, dlt;
+    if (q < S::NB * S::H) { b = q / S::H; dlt = q % S::H; }
+    else {
+        if (!S::has_extra(w)) return;
+        b = S::extra_base(w); dlt = S::H;
+    }
+    const int fa = S::NB * w + b, fb = (fa + dlt) % F;
+    double s = 0.0;
+    for (long gseg = 0; gseg < nseg; gseg++) s += partial[(((size_t)gseg * S::NACT + w) * S::NS + q) * 256 + e];
+    const int row = 16 * fa + (l >> 4) + 4 * r, col = 16 * fb + (l & 15);
+    if (row < p && col < p) {
+        const double v = s / denom;
+        var[row + (size_t)p * col] = v;
+        var[col + (size_t)p * row] = v;
+    }
+}
+
+template <int F>
+static int launch_olbm_mfma(const double *x, long n, int p, long len, long nwin, const double *dmean, double *dvar,
+                            DeviceCtx *dc)
+{
+    using S = OmShape<F>;
+    hipStream_t s = dc->stream;
+    auto kern = olbm_mfma_kernel<F>;
+    if (S::lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)S::lds_bytes));
+    // segments: exactly one round of resident workgroups.  Every workgroup does the same work (a seed of
+    // len loads per column, then 2 loads per window and column), so one round of equal segments finishes
+    // together; more, shorter segments would only repeat the seed.
+    int bpc = 1;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, reinterpret_cast<const void *>(kern), 64 * OM_NW,
+                                                         S::lds_bytes));
+    if (bpc < 1) bpc = 1;
+    const long resident = (long)bpc * dc->num_cu;
+    long seg = (nwin + resident - 1) / resident;
+    if (seg < 16L * OM_SLAB) seg = 16L * OM_SLAB;
+    seg = ((seg + OM_SLAB - 1) / OM_SLAB) * OM_SLAB;
+    const long nseg = (nwin + seg - 1) / seg;
+    DevBuf part;
+    HIP_TRY(part.alloc((size_t)nseg * S::NACT * S::NS * 256 * 8));
+    timing_reset("olbm_mfma_kernel");
+    timing_begin(s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nseg), dim3(64 * OM_NW), S::lds_bytes, s, x, n, p, len, nwin, seg, dmean,
+                       part.as<double>());
+    timing_end(s);
+    HIP_TRY(hipGetLastError());
+    const double denom = (double)nwin * (double)n * (double)len;
+    hipLaunchKernelGGL(olbm_mfma_finish_kernel<F>, dim3((unsigned)(S::NACT * S::NS)), dim3(256), 0, s,
+                       part.as<double>(), nseg, p, denom, dvar);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));       // part is released on return
+    return MCMCHIP_OK;
 }
 
 int run_olbm(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc)
 {
     hipStream_t s = dc->stream;
+    if (n >= (1L << 31)) return set_error(MCMCHIP_EINVAL, "olbm: n exceeds the reference's int range (olbm.c:25)");
     DevBuf dmean, dvar, part, cpart;
     HIP_TRY(dmean.alloc((size_t)p * 8));
     HIP_TRY(dvar.alloc((size_t)p * p * 8));
@@ -334,14 +623,29 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
         HIP_TRY(hipGetLastError());
     }
     const long nwin = n - len + 1;
-    const long seg = (long)OL_SLAB * OL_SEG_SLABS;
-    const long nseg = (nwin + seg - 1) / seg;
-    const int nt = (p + 15) / 16;
+    if (p <= 256) {
+        int rc;
+        if (p <= 64) rc = launch_olbm_mfma<4>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
+        else if (p <= 128) rc = launch_olbm_mfma<8>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
+        else rc = launch_olbm_mfma<16>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(var, dvar.p, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
+        if (!nocalc) HIP_TRY(hipMemcpyAsync(mean, dmean.p, (size_t)p * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return MCMCHIP_OK;
+    }
+    const int nt = (p + OL_CT - 1) / OL_CT;
     const int npairs = nt * (nt + 1) / 2;
-    HIP_TRY(part.alloc((size_t)nseg * npairs * 256 * 8));
+    // segments: about 8 workgroups per CU over all tile pairs, at least 16 slabs each
+    long want_seg = (8L * dc->num_cu + npairs - 1) / npairs;
+    long seg = (nwin + want_seg - 1) / want_seg;
+    if (seg < 16L * OL_SLAB) seg = 16L * OL_SLAB;
+    seg = ((seg + OL_SLAB - 1) / OL_SLAB) * OL_SLAB;
+    const long nseg = (nwin + seg - 1) / seg;
+    HIP_TRY(part.alloc((size_t)nseg * npairs * OL_CT * OL_CT * 8));
     timing_reset("olbm_kernel");
     timing_begin(s);
-    hipLaunchKernelGGL(olbm_kernel, dim3((unsigned)nseg, (unsigned)npairs), dim3(256), 0, s, x, n, p, len, nwin,
+    hipLaunchKernelGGL(olbm_kernel, dim3((unsigned)nseg, (unsigned)npairs), dim3(256), 0, s, x, n, p, len, nwin, seg,
                        dmean.as<double>(), npairs, part.as<double>());
     timing_end(s);
     HIP_TRY(hipGetLastError());

@@ -418,7 +418,9 @@ def test_initseq_edge_cases(api, oracle_mod):
         api.initseq(np.array([1.0, np.nan, 2.0]))
 
 
-@pytest.mark.parametrize("n,p,blen", [(20000, 3, 25), (5000, 40, 500), (1000, 1, 1), (300, 17, 300), (70000, 16, 1000)])
+@pytest.mark.parametrize("n,p,blen", [(20000, 3, 25), (5000, 40, 500), (1000, 1, 1), (300, 17, 300), (70000, 16, 1000),
+                                       (9000, 100, 77), (6000, 150, 64), (5000, 200, 33), (4100, 256, 100),
+                                       (2500, 300, 50), (37, 65, 5)])
 def test_olbm_vs_oracle(api, oracle_mod, n, p, blen):
     rng = np.random.default_rng(n + p)
     e = rng.standard_normal((n, p)) + 3.0

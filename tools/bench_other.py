@@ -78,11 +78,10 @@ def c4():
     return out
 
 
-def c5():
-    """initseq + olbm on AR(1) columns resident in HBM (reduced size: n = 4e6 x p = 32 = 1 GB)"""
+def c5(n=4_000_000, p=32, blens=(1000,)):
+    """initseq + olbm on AR(1) columns resident in HBM (reduced sizes: 4e6 x 32 = 1 GB, 2e6 x 256 = 4 GB)"""
     import torch
     from scipy.signal import lfilter
-    n, p = 4_000_000, 32
     rng = np.random.default_rng(5)
     rho = 0.5 + 0.49 * np.arange(p) / (p - 1)
     x = np.empty((p, n))                       # column-major n x p
@@ -113,7 +112,7 @@ def c5():
                 "var_con_over_gamma0": [float(v) for v in (vc / g0)[:4]]})
     mean = np.zeros(p)
     var = np.empty((p, p))
-    for blen in (1000,):
+    for blen in blens:
         for rep in range(2):
             t0 = time.perf_counter()
             rc = L.mcmchip_olbm(xd.data_ptr(), n, p, blen, mean.ctypes.data, var.ctypes.data, 0, 1)
@@ -129,6 +128,10 @@ def c5():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c4", "c5"]
     for w in which:
-        r = {"c2": c2, "c4": c4, "c5": c5}[w]()
+        if w.startswith("c5="):            # c5=n,p,len[,len...]
+            a = [int(v) for v in w[3:].split(",")]
+            r = c5(a[0], a[1], tuple(a[2:]))
+        else:
+            r = {"c2": c2, "c4": c4, "c5": c5, "c5p256": lambda: c5(2_000_000, 256)}[w]()
         for line in (r if isinstance(r, list) else [r]):
             print(json.dumps(line))
