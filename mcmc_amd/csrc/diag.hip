@@ -360,12 +360,15 @@ __global__ void olbm_finish_kernel(const double *__restrict__ partial, long nseg
 // ---------------------------------------------------------------------------------------------
 // p <= 256: all columns in one workgroup, outer products on the fp64 matrix cores.
 // var = V^T V with V[w][c] = (window sum of column c starting at w) - len*mean[c]: a GEMM whose K axis
-// is the window index.  One workgroup (8 waves) walks a segment of windows in 32-window slabs:
-//   load   lanes = consecutive windows: coalesced 256-B runs of x[t+len] - x[t]  -> LDS D[window][col]
-//   scan   one thread per column turns D into the centred window sums in place (olbm.c:61-62 recurrence,
-//          so the rounding is the reference's within a segment)
-//   mfma   v_mfma_f64_16x16x4 on 16-column fragments V[4 windows][16 cols].
-// The next slab's global loads are in flight during scan + mfma.
+// is the window index.  One workgroup (8 waves) walks a segment of windows in 16-window slabs through a
+// double-buffered LDS image V[2][16 windows][columns]; there is one barrier per slab and no separate
+// producer phase: inside the mfma loop of slab s every wave also
+//   - turns the raw loads of slab s+1 (in registers since the previous iteration) into window sums:
+//     x[t+len] - x[t] (olbm.c:61-62), an inclusive prefix over the 16 lanes of a DPP row (lanes = consecutive
+//     windows of one column, 4 columns per wave-load), plus the running sum the thread keeps per column,
+//   - writes them to the other V buffer, and
+//   - issues the global loads of slab s+2,
+// so HBM latency, the scan and the LDS writes all hide behind the matrix pipe.
 //
 // Tile schedule.  With F fragments (F*16 >= p columns) var has F(F+1)/2 distinct 16 x 16 tiles; a tile is
 // an unordered fragment pair, so they are taken as the circulant family {f, (f+delta) mod F},
@@ -374,7 +377,7 @@ __global__ void olbm_finish_kernel(const double *__restrict__ partial, long nseg
 // that is exactly 17 tiles on each of the 8 waves.  The columns of the first F/2+1 fragments are stored
 // a second time after column 16F, so (f+delta) never wraps: every fragment a wave needs in a k-step sits
 // at (one base register) + (compile-time offset) and a k-step costs NB + F/2 ds_read_b64 for its MFMAs.
-#define OM_SLAB 32
+#define OM_SLAB 16
 #define OM_NW 8
 
 typedef double om_double4 __attribute__((ext_vector_type(4)));
@@ -386,13 +389,25 @@ template <int F> struct OmShape {
     static constexpr int NS = NB * H + 1;               // accumulator tiles per wave (last = the delta = H tile)
     static constexpr int NFR = NB + H;                  // fragments read per k-step
     static constexpr int PP = F * 16;
-    static constexpr int LD = PP + (H + 1) * 16 + 1;    // odd: conflict-free transposed writes and fragment reads
-    static constexpr int NLD = PP / (2 * OM_NW);        // columns each thread loads per slab
+    static constexpr int DUPC = (H + 1) * 16;           // columns stored twice
+    // LD = 2 mod 4: the two fragment rows a 32-lane ds_read_b64 group touches are 8 rows = 32 banks apart
+    // (conflict-free); the transposed ds_write_b64 of the producer is 2-way, off the critical path
+    static constexpr int LD = PP + DUPC + 2;
+    static constexpr int NLD = PP / (4 * OM_NW);        // columns each thread produces per slab
     // the delta = H tile of wave w: base index and whether the wave has one
     __host__ __device__ static constexpr int extra_base(int w) { return NB == 2 ? (w < NACT / 2 ? 0 : 1) : 0; }
     __host__ __device__ static constexpr bool has_extra(int w) { return NB == 2 ? true : w < NACT / 2; }
-    static constexpr size_t lds_bytes = ((size_t)OM_SLAB * LD + PP) * 8;
+    static constexpr size_t lds_bytes = ((size_t)2 * OM_SLAB * LD + PP) * 8;
 };
+
+// row_shr:N within the 16 lanes of a DPP row, zero fill
+template <int N> __device__ __forceinline__ double om_row_shr(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 
 template <int F>
 __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__restrict__ x, long n, int p, long len,
@@ -401,10 +416,10 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
                                                                double *__restrict__ partial)
 {
     using S = OmShape<F>;
-    constexpr int LD = S::LD, PP = S::PP, H = S::H, NB = S::NB;
+    constexpr int LD = S::LD, PP = S::PP, H = S::H, NB = S::NB, NLD = S::NLD;
     extern __shared__ double om_sm[];
-    double *V = om_sm;                       // [OM_SLAB][LD]
-    double *run = om_sm + OM_SLAB * LD;      // [PP] centred sum of the window that starts the next slab
+    double *V = om_sm;                           // [2][OM_SLAB][LD]
+    double *run = om_sm + 2 * OM_SLAB * LD;      // [PP] seeds
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const long w_begin = (long)blockIdx.x * seg_windows;
     long w_end = w_begin + seg_windows;
@@ -436,76 +451,79 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
             if (lane == 0 && c < PP) run[c] = c < p ? sv : 0.0;
         }
     }
+    __syncthreads();
 
     om_double4 acc[S::NS];
 #pragma unroll
     for (int q = 0; q < S::NS; q++) acc[q] = om_double4{0.0, 0.0, 0.0, 0.0};
     // the K index of the GEMM is a dummy: lane group g = lane/16 of k-step ks takes window row
-    // 2*ks + g/2 + 16*(g%2), so the two groups that share a 32-lane LDS access are 16 rows apart
-    // = 32 banks apart with an odd LD: ds_read_b64 is conflict-free (bank = (addr/4) % 64).
+    // 2*ks + g/2 + 8*(g%2)
     const int g = lane >> 4;
-    const double *Vw = V + ((g >> 1) + 16 * (g & 1)) * LD + (lane & 15) + 16 * NB * wave;
+    const double *Vw = V + ((g >> 1) + 8 * (g & 1)) * LD + (lane & 15) + 16 * NB * wave;
     const bool mfma_wave = wave < S::NACT;
     const bool extra_on_b1 = S::extra_base(wave) == 1, extra = S::has_extra(wave);
 
-    // load phase: lanes 0-31 / 32-63 = 32 consecutive windows of two adjacent columns.
+    // producer: lane = (column cs of 4, window wl of 16); column of slot q is q*32 + wave*4 + cs.
     // address = (wave-uniform 64-bit base) + (32-bit lane offset): no per-column pointer registers
-    const int sub = lane >> 5, wl = lane & 31;
-    const unsigned lane_lo = (unsigned)((size_t)sub * n + wl), lane_hi = lane_lo + (unsigned)len;
-    // the raw loads stay in registers (not their difference) so that nothing waits on them until the
-    // next slab's D write: their HBM latency hides behind the scan and mfma phases
-    double hi[S::NLD], lo[S::NLD];
-    auto load_slab = [&](long w0) {
-        const bool ok = w0 + wl + len < n;
+    const int cs = lane >> 4, wl = lane & 15;
+    const unsigned lane_lo = (unsigned)((size_t)cs * n + wl), lane_hi = lane_lo + (unsigned)len;
+    double hi[NLD], lo[NLD], runq[NLD];
 #pragma unroll
-        for (int q = 0; q < S::NLD; q++) {
-            const int c = q * 2 * OM_NW + wave * 2 + sub;
-            const double *xq = x + (size_t)(q * 2 * OM_NW + wave * 2) * n + w0;      // uniform
-            hi[q] = 0.0;
-            lo[q] = 0.0;
-            if (c < p && ok) {
-                hi[q] = xq[lane_hi];
-                lo[q] = xq[lane_lo];
-            }
-        }
+    for (int q = 0; q < NLD; q++) runq[q] = run[q * 4 * OM_NW + wave * 4 + cs];
+    // Raw loads through a buffer descriptor rebuilt per (slot, slab) in scalar registers: the hardware range
+    // check returns 0 past the end of x, so the load needs no branch and no per-lane address arithmetic.
+    // What it reads for columns >= p or for windows past the end is real memory of other columns: it only
+    // reaches rows/columns of V that the masks below and the finish kernel (row, col < p) discard.
+    const unsigned off_lo = lane_lo * 8u, off_hi = lane_hi * 8u;
+    const long total = (long)n * p;
+    auto load_q = [&](int q, long w0) {
+        const long first = (long)(q * 4 * OM_NW + wave * 4) * n + w0;          // uniform
+        long rem = (total - first) * 8;
+        rem = rem < 0 ? 0 : (rem > 0xffffffffL ? 0xffffffffL : rem);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(x + (first < total ? first : 0)), 0, (int)(unsigned)rem, 0x00020000);
+        hi[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, off_hi, 0, 0));
+        lo[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, off_lo, 0, 0));
     };
-    load_slab(w_begin);
+    // window sums of slab w0 for slot q -> Vdst (and the duplicate columns).  Straight-line code (selects,
+    // no branches) so that the scheduler can spread it between the MFMAs of a k-step.
+    auto produce = [&](int q, long w0, double *Vdst) {
+        const double d = hi[q] - lo[q];
+        double inc = d;
+        inc += om_row_shr<1>(inc);
+        inc += om_row_shr<2>(inc);
+        inc += om_row_shr<4>(inc);
+        inc += om_row_shr<8>(inc);
+        const double excl = om_row_shr<1>(inc);
+        const double tot = __shfl(inc, lane | 15, 64);
+        const double vs = runq[q] + excl;
+        const bool valid = w0 + wl < w_end;
+        const double v = __hiloint2double(valid ? __double2hiint(vs) : 0, valid ? __double2loint(vs) : 0);
+        runq[q] += tot;
+        const int c = q * 4 * OM_NW + wave * 4 + cs;
+        Vdst[wl * LD + c] = v;
+        // duplicate columns: always / never by slot where that is known, else steered to the row's padding
+        if (q * 4 * OM_NW + (OM_NW - 1) * 4 < S::DUPC) Vdst[wl * LD + PP + c] = v;
+        else if (q * 4 * OM_NW < S::DUPC) Vdst[wl * LD + (q * 4 * OM_NW + wave * 4 < S::DUPC ? PP + c : PP + S::DUPC)] = v;
+    };
 
-#ifdef OM_PROF
-    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter(), tn;
-#define OM_TICK(i) { tn = __builtin_readcyclecounter(); tp[i] += tn - tc; tc = tn; }
-#else
-#define OM_TICK(i)
-#endif
-    for (long w0 = w_begin; w0 < w_end; w0 += OM_SLAB) {
-        __syncthreads();                     // previous slab's fragments are consumed; run[] is written
-        OM_TICK(0)
 #pragma unroll
-        for (int q = 0; q < S::NLD; q++) V[wl * LD + q * 2 * OM_NW + wave * 2 + sub] = hi[q] - lo[q];
-        if (w0 + OM_SLAB < w_end) load_slab(w0 + OM_SLAB);
-        OM_TICK(1)
-        __syncthreads();
-        OM_TICK(2)
-        if (tid < PP) {
-            double r = run[tid];
-            const bool dup = tid < (H + 1) * 16;
-#pragma unroll 8
-            for (int s2 = 0; s2 < OM_SLAB; s2++) {
-                const double d = V[s2 * LD + tid];
-                const double v = (w0 + s2 < w_end) ? r : 0.0;
-                V[s2 * LD + tid] = v;
-                if (dup) V[s2 * LD + PP + tid] = v;
-                r += d;
-            }
-            run[tid] = r;
-        }
-        OM_TICK(3)
-        __syncthreads();
-        OM_TICK(4)
-        if (mfma_wave) {
-#pragma unroll 2
-            for (int ks = 0; ks < OM_SLAB / 4; ks++) {
-                const double *Vk = Vw + 2 * ks * LD;
+    for (int q = 0; q < NLD; q++) load_q(q, w_begin);
+#pragma unroll
+    for (int q = 0; q < NLD; q++) produce(q, w_begin, V);
+#pragma unroll
+    for (int q = 0; q < NLD; q++) load_q(q, w_begin + OM_SLAB);
+    __syncthreads();
+
+    constexpr bool all_mfma = S::NACT == OM_NW;
+    int cur = 0;
+    for (long w0 = w_begin; w0 < w_end; w0 += OM_SLAB, cur ^= 1) {
+        const double *Vc = Vw + cur * (OM_SLAB * LD);
+        double *Vn = V + (cur ^ 1) * (OM_SLAB * LD);
+#pragma unroll
+        for (int ks = 0; ks < OM_SLAB / 4; ks++) {
+            if (all_mfma || mfma_wave) {
+                const double *Vk = Vc + 2 * ks * LD;
                 double fr[S::NFR];
 #pragma unroll
                 for (int i = 0; i < S::NFR; i++) fr[i] = Vk[16 * i];
@@ -517,18 +535,30 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
                 if constexpr (NB == 2) {     // every wave has one: operands picked by a wave-uniform select
                     const double ea = extra_on_b1 ? fr[1] : fr[0], eb = extra_on_b1 ? fr[1 + H] : fr[H];
                     acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea, eb, acc[NB * H], 0, 0, 0);
-                } else if (extra) {
+                } else {                     // waves without a delta = H tile compute one nobody reads
                     acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[0], fr[H], acc[NB * H], 0, 0, 0);
                 }
             }
+            // a share of the next slab's production, and of the loads of the one after, rides in the shadow
+            // of this k-step's MFMAs: the matrix pipe runs an MFMA for 64 cycles while the wave issues on
+#pragma unroll
+            for (int q = 0; q < NLD; q++)
+                if (q * (OM_SLAB / 4) / NLD == ks && (NLD >= OM_SLAB / 4 || ks * NLD % (OM_SLAB / 4) == 0)) {
+                    produce(q, w0 + OM_SLAB, Vn);
+                    load_q(q, w0 + 2 * OM_SLAB);
+                }
+            if constexpr (all_mfma) {
+#pragma unroll
+                for (int i = 0; i < S::NS; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // a few VALU of the producer
+                    if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);   // an LDS op
+                    if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
+                }
+            }
         }
-        OM_TICK(5)
+        __syncthreads();
     }
-#ifdef OM_PROF
-    if (blockIdx.x == 3 && lane == 0 && (wave == 0 || wave == 7))
-        printf("wave %d: topbarrier %llu dwrite %llu bar2 %llu scan %llu bar3 %llu mfma %llu\n", wave, tp[0], tp[1], tp[2],
-               tp[3], tp[4], tp[5]);
-#endif
     // partial[segment][wave][slot][reg][lane]
     if (mfma_wave) {
         double *out = partial + ((size_t)blockIdx.x * S::NACT + wave) * S::NS * 256;
@@ -623,7 +653,7 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
         HIP_TRY(hipGetLastError());
     }
     const long nwin = n - len + 1;
-    if (p <= 256) {
+    if (p <= 256 && 8 * (3 * n + len + 64) < (1L << 32)) {      // 32-bit byte offsets in the matrix-core kernel
         int rc;
         if (p <= 64) rc = launch_olbm_mfma<4>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
         else if (p <= 128) rc = launch_olbm_mfma<8>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
