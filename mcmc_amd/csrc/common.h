@@ -57,6 +57,12 @@ struct DevBuf {
         bytes = n;
         return hipMalloc(&p, n ? n : 8);
     }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
     template <class T> T *as() { return (T *)p; }
 };
 

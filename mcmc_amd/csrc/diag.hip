@@ -3,20 +3,18 @@
 // initseq (reference initseq.c:7-128): the O(len x lags) double sum of lag products
 // (initseq.c:24-47) is the hot loop; the monotone / convex post-processing (55-105) works on a
 // few hundred numbers and stays on the host, in the reference's own sequential order.
-//   autocov_kernel streams a column once per block of 32 lags: a workgroup stages a 2048-element
-//   tile (plus a lag-shifted tile with a 32-element halo) in LDS, each lane keeps an 8 x 40
-//   register window and 32 accumulators, so one pass costs 8 B/element of HBM for 32 lags
-//   (16 flop/byte: the pass is fp64-VALU-bound; lags are produced speculatively in blocks
-//   because the stopping lag (first negative Gamma, initseq.c:42-46) is data dependent).
-//   LDS rows are padded by one double per 8 so the per-lane windows (stride 9 doubles) are
-//   bank-conflict-free for ds_read_b64.  Partial sums are reduced in a fixed order.
+//   autocov_kernel<NJ> computes NJ*16 consecutive lags of one column per work item on the fp64 matrix
+//   cores (v_mfma_f64_4x4x4_f64, every multiply-add of the instruction a wanted lag product; see the
+//   comment at the kernel).  Lags are produced speculatively in units of 64 because the stopping lag
+//   (first negative Gamma, initseq.c:42-46) is data dependent.  Partial sums are reduced in a fixed order.
 //
 // olbm (reference olbm.c:22-78): sliding window sums and the p x p sum of outer products.
-//   Window sums are rebuilt per 64-window slab from a wave prefix scan of x[t+len]-x[t]
-//   (coalesced along time because x is column-major), seeded per time segment by a direct
-//   centred sum, so rounding does not accumulate along n as in the reference's running
-//   recurrence (olbm.c:61-62).  Each workgroup owns one 64 x 64 tile pair of the lower triangle,
-//   4 x 4 outputs per lane in registers (fp64 MFMA has no rate advantage over fp64 FMA on gfx950).
+//   p <= 256: olbm_mfma_kernel, all columns in one workgroup, var = V^T V on v_mfma_f64_16x16x4_f64 with
+//   the window sums V rebuilt on the fly (see the comment at the kernel).  Window sums are seeded per
+//   time segment by a direct centred sum, so rounding does not accumulate along n as in the reference's
+//   running recurrence (olbm.c:61-62).
+//   p > 256: olbm_kernel, one workgroup per 64 x 64 tile pair of the lower triangle, 4 x 4 outputs per
+//   lane in registers.
 #include "kernels.h"
 #include <math.h>
 #include <vector>
@@ -24,62 +22,104 @@
 // =============================================================================================
 // initseq
 // =============================================================================================
-#define IS_R 8
-#define IS_B 32
-#define IS_TILE (256 * IS_R)
+#define IS_B 64                 // lags per work unit
+#define IS_TILE 2048            // base positions per LDS tile
 #define IS_TILES_PER_BLOCK 32
 
+// Lag products on the fp64 matrix cores.  v_mfma_f64_4x4x4_f64 is four independent 4x4x4 products
+// (lane = q + 4*blk + 16*k: A_blk[i=q][k], B_blk[k][j=q]; result lane = j + 4*blk + 16*i; layout and a rate
+// equal to the 16x16x4 form measured by tools/mfma64_4x4_probe.hip).  With
+//     A_blk[i][k] = x[u + i + blk + 4k]          B_blk[k][j] = x[u + blk + 4k + 4j + 3 + L]
+// entry (i, j) accumulates x[t] * x[t + lag] for lag = L + 4j + 3 - i (16 consecutive lags) over the 16 base
+// positions t = u + i + (blk + 4k): every one of the 256 multiply-adds of the instruction is a wanted lag
+// product, and stepping u by 16 tiles the series exactly once.  Both operands are ~20 consecutive doubles
+// of one LDS image (conflict-free, mostly broadcast), and B(u + 16, L) = B(u, L + 16): a wave that walks u
+// in order keeps the B fragments of its NJ lag blocks in registers and reads one new A and one new B
+// fragment per NJ MFMAs.  A workgroup stages a 2048-position tile (plus the lag-shifted image) in LDS, its
+// 4 waves take 512 positions each, and the next tile's global loads are in flight while this one is
+// multiplied.  Accumulators: one double per lane per 16 lags, so a work item spans NJ*16 = 64 or 256 lags.
+// (initseq.c:24-47; the sums are the reference's up to summation order.)
+template <int NJ>
 __global__ __launch_bounds__(256) void autocov_kernel(const double *__restrict__ x, long len, const int *__restrict__ cols,
-                                                      long lag_first, long nblk, int nlb, double *__restrict__ partial)
+                                                      const long *__restrict__ lag_of, const int *__restrict__ unit_of,
+                                                      long nblk, double *__restrict__ partial)
 {
-    __shared__ double A[IS_TILE + IS_TILE / 8];
-    __shared__ double Bt[IS_TILE + IS_B + (IS_TILE + IS_B) / 8 + 8];
-    __shared__ double red[4][IS_B];
-    const int t = threadIdx.x;
-    const int col = cols[blockIdx.z];
-    const int lb = blockIdx.y;
-    const long lag0 = lag_first + (long)lb * IS_B;
+    constexpr int NA = IS_TILE + 32, NB_ = IS_TILE + 16 * NJ + 32;
+    constexpr int LA = (NA + 255) / 256, LB = (NB_ + 255) / 256;
+    __shared__ double PA[NA];
+    __shared__ double PB[NB_];
+    __shared__ double red[4][16 * NJ];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    // work item = (column, NJ*16 lags) on grid.x, time range on grid.y: the items of one column over one time
+    // range are dispatched together, so all but the first read of a tile hit L2 / MALL
+    const int col = cols[blockIdx.x];
+    const long lag0 = lag_of[blockIdx.x];
     const double *xs = x + (size_t)col * len;
-    double acc[IS_B];
+    double acc[NJ];
 #pragma unroll
-    for (int k = 0; k < IS_B; k++) acc[k] = 0.0;
+    for (int j = 0; j < NJ; j++) acc[j] = 0.0;
+    const int q = lane & 3, blk = (lane >> 2) & 3, k = lane >> 4;
+    const int offA = q + blk + 4 * k, offB = blk + 4 * k + 4 * q;
 
-    for (int tile = 0; tile < IS_TILES_PER_BLOCK; tile++) {
-        const long a = ((long)blockIdx.x * IS_TILES_PER_BLOCK + tile) * IS_TILE;
-        if (a >= len) break;
-        for (int e = t; e < IS_TILE; e += 256) {
+    double ra[LA], rb[LB];
+    auto fetch = [&](long a) {                  // tile base a (may be -16): zero outside [0, len)
+#pragma unroll
+        for (int i = 0; i < LA; i++) {
+            const int e = t + 256 * i;
             const long idx = a + e;
-            A[e + (e >> 3)] = idx < len ? xs[idx] : 0.0;
+            ra[i] = (e < NA && idx >= 0 && idx < len) ? xs[idx] : 0.0;
         }
-        for (int e = t; e < IS_TILE + IS_B; e += 256) {
-            const long idx = a + lag0 + e;
-            Bt[e + (e >> 3)] = idx < len ? xs[idx] : 0.0;
+#pragma unroll
+        for (int i = 0; i < LB; i++) {
+            const int e = t + 256 * i;
+            const long idx = a + lag0 + 3 + e;
+            rb[i] = (e < NB_ && idx >= 0 && idx < len) ? xs[idx] : 0.0;
         }
+    };
+    const long first = (long)blockIdx.y * IS_TILES_PER_BLOCK * IS_TILE - 16;
+    fetch(first);
+    for (int tile = 0; tile < IS_TILES_PER_BLOCK; tile++) {
+        const long a = first + (long)tile * IS_TILE;
+        if (a >= len) break;
+        __syncthreads();                        // the previous tile's fragments are consumed
+#pragma unroll
+        for (int i = 0; i < LA; i++)
+            if (t + 256 * i < NA) PA[t + 256 * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; i++)
+            if (t + 256 * i < NB_) PB[t + 256 * i] = rb[i];
         __syncthreads();
-        double wa[IS_R], wb[IS_R + IS_B];
+        if (tile + 1 < IS_TILES_PER_BLOCK && a + IS_TILE < len) fetch(a + IS_TILE);
+        const double *pa = PA + wave * (IS_TILE / 4) + offA;
+        const double *pb = PB + wave * (IS_TILE / 4) + offB;
+        double R[NJ];                           // R[m % NJ] = B fragment at u + 16 m
 #pragma unroll
-        for (int m = 0; m < IS_R; m++) wa[m] = A[t * 9 + m];
+        for (int m = 0; m < NJ - 1; m++) R[m] = pb[16 * m];
+        for (int s0 = 0; s0 < IS_TILE / 4 / 16; s0 += NJ) {
 #pragma unroll
-        for (int m = 0; m < IS_R + IS_B; m++) wb[m] = Bt[t * 9 + m + (m >> 3)];
+            for (int ss = 0; ss < NJ; ss++) {
+                const int s_ = s0 + ss;
+                const double fa = pa[16 * s_];
+                R[(ss + NJ - 1) % NJ] = pb[16 * (s_ + NJ - 1)];
 #pragma unroll
-        for (int i = 0; i < IS_R; i++)
-#pragma unroll
-            for (int k = 0; k < IS_B; k++) acc[k] = fma(wa[i], wb[i + k], acc[k]);
-        __syncthreads();
+                for (int j = 0; j < NJ; j++)
+                    acc[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, R[(ss + j) % NJ], acc[j], 0, 0, 0);
+            }
+        }
     }
-    // fixed-shape reduction: xor butterfly inside the wave, then the 4 waves in order
-    const int wave = t >> 6, lane = t & 63;
+    // the four blk groups of a wave, then the 4 waves in order
 #pragma unroll
-    for (int k = 0; k < IS_B; k++) {
-        double v = acc[k];
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-        if (lane == 0) red[wave][k] = v;
+    for (int j = 0; j < NJ; j++) {
+        double v = acc[j];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if (blk == 0) red[wave][16 * j + 4 * q + 3 - k] = v;     // result lane = j' + 4*blk + 16*i: q = j', k = i
     }
     __syncthreads();
-    if (t < IS_B) {
+    if (t < 16 * NJ) {
         const double v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
-        partial[(((size_t)blockIdx.z * nlb + lb) * nblk + blockIdx.x) * IS_B + t] = v;
+        const int unit = unit_of[blockIdx.x] + t / IS_B;
+        partial[((size_t)unit * nblk + blockIdx.y) * IS_B + t % IS_B] = v;
     }
 }
 
@@ -134,32 +174,77 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
 {
     hipStream_t s = dc->stream;
     const long half = len / 2;
-    const long nblk = (len + (long)IS_TILE * IS_TILES_PER_BLOCK - 1) / ((long)IS_TILE * IS_TILES_PER_BLOCK);
-    const int NLB_MAX = 8;
-    DevBuf partial, sums, dcols;
-    HIP_TRY(partial.alloc((size_t)ncol * NLB_MAX * nblk * IS_B * 8));
-    HIP_TRY(sums.alloc((size_t)ncol * NLB_MAX * IS_B * 8));
-    HIP_TRY(dcols.alloc((size_t)ncol * sizeof(int)));
+    // tiles start at position -16 (zero padded), so the 4 result rows of an MFMA see every base position
+    const long span = (long)IS_TILE * IS_TILES_PER_BLOCK;
+    const long nblk = (len + 16 + span - 1) / span;
+    if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
+    // The stopping lag (first negative Gamma, initseq.c:42-46) is data dependent, so lags are produced
+    // speculatively in units of 64: every column starts with one unit and, while still active, gets as
+    // many new lags as it already has (at most 1024 per launch): at most ~2x the lag products a
+    // clairvoyant run would need.  Four consecutive units of a column go to one 256-lag work item.
+    const long MAX_UNITS_PER_LAUNCH = 16;
+    size_t cap_units = 0;
+    DevBuf partial, sums, dcols, dlags, dunits;
     std::vector<std::vector<double>> Gam((size_t)ncol);   // Gamma_i per column, as far as computed
     std::vector<long> done((size_t)ncol, -1);            // output length once the stop rule fired
+    std::vector<long> have((size_t)ncol, 0);             // lags computed so far
     std::vector<double> g0((size_t)ncol, 0.0);
     std::vector<int> active;
     for (long c = 0; c < ncol; c++) active.push_back((int)c);
     std::vector<double> host;
-    long lag_first = 0;
-    int nlb = 2;
+    std::vector<int> unit_col;                            // per 64-lag unit, in (column, lag) order
+    std::vector<int> item_col[2], item_unit[2];           // work items: [0] = 1 unit (NJ = 4), [1] = 4 units (NJ = 16)
+    std::vector<long> item_lag[2];
     timing_reset("autocov_kernel");
     if (half == 0) active.clear();
     while (!active.empty()) {
-        const long nact = (long)active.size();
-        HIP_TRY(hipMemcpyAsync(dcols.p, active.data(), (size_t)nact * sizeof(int), hipMemcpyHostToDevice, s));
-        dim3 grid((unsigned)nblk, (unsigned)nlb, (unsigned)nact);
-        timing_begin(s);
-        hipLaunchKernelGGL(autocov_kernel, grid, dim3(256), 0, s, x, len, dcols.as<int>(), lag_first, nblk, nlb,
-                           partial.as<double>());
-        timing_end(s);
-        HIP_TRY(hipGetLastError());
-        const long total = nact * nlb * IS_B;
+        unit_col.clear();
+        for (int w = 0; w < 2; w++) { item_col[w].clear(); item_unit[w].clear(); item_lag[w].clear(); }
+        for (int c : active) {
+            long nb = have[(size_t)c] == 0 ? 1 : have[(size_t)c] / IS_B;
+            if (nb > MAX_UNITS_PER_LAUNCH) nb = MAX_UNITS_PER_LAUNCH;
+            const long need = (2 * half - have[(size_t)c] + IS_B - 1) / IS_B;   // never past lag 2*half
+            if (nb > need) nb = need;
+            for (long b = 0; b < nb;) {
+                const int w = nb - b >= 4 ? 1 : 0, nu = w ? 4 : 1;
+                item_col[w].push_back(c);
+                item_unit[w].push_back((int)unit_col.size());
+                item_lag[w].push_back(have[(size_t)c] + b * IS_B);
+                for (int u = 0; u < nu; u++) unit_col.push_back(c);
+                b += nu;
+            }
+        }
+        const long nitem = (long)unit_col.size();         // units
+        if ((size_t)nitem > cap_units) {          // grow the work buffers (freed and re-made: sizes follow the work list)
+            partial.release(); sums.release(); dcols.release(); dlags.release(); dunits.release();
+            cap_units = (size_t)nitem;
+            HIP_TRY(partial.alloc(cap_units * nblk * IS_B * 8));
+            HIP_TRY(sums.alloc(cap_units * IS_B * 8));
+            HIP_TRY(dcols.alloc(cap_units * sizeof(int)));
+            HIP_TRY(dlags.alloc(cap_units * sizeof(long)));
+            HIP_TRY(dunits.alloc(cap_units * sizeof(int)));
+        }
+        size_t off = 0;
+        for (int w = 0; w < 2; w++) {
+            const size_t ni = item_col[w].size();
+            if (!ni) continue;
+            HIP_TRY(hipMemcpyAsync(dcols.as<int>() + off, item_col[w].data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(dlags.as<long>() + off, item_lag[w].data(), ni * sizeof(long), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(dunits.as<int>() + off, item_unit[w].data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
+            dim3 grid((unsigned)ni, (unsigned)nblk);
+            timing_begin(s);
+            if (w == 0)
+                hipLaunchKernelGGL(autocov_kernel<4>, grid, dim3(256), 0, s, x, len, dcols.as<int>() + off,
+                                   dlags.as<long>() + off, dunits.as<int>() + off, nblk, partial.as<double>());
+            else
+                hipLaunchKernelGGL(autocov_kernel<16>, grid, dim3(256), 0, s, x, len, dcols.as<int>() + off,
+                                   dlags.as<long>() + off, dunits.as<int>() + off, nblk, partial.as<double>());
+            timing_end(s);
+            HIP_TRY(hipGetLastError());
+            off += ni;
+        }
+        const std::vector<int> &item_col_flat = unit_col;
+        const long total = nitem * IS_B;
         hipLaunchKernelGGL(autocov_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                            partial.as<double>(), nblk, total, sums.as<double>());
         HIP_TRY(hipGetLastError());
@@ -167,11 +252,14 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
         HIP_TRY(hipMemcpyAsync(host.data(), sums.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         std::vector<int> next;
-        for (long a = 0; a < nact; a++) {
-            const int c = active[(size_t)a];
-            const double *g = host.data() + (size_t)a * nlb * IS_B;   // lags lag_first .. lag_first + nlb*32
+        long it = 0;
+        for (int c : active) {
+            long nb = 0;
+            while (it + nb < nitem && item_col_flat[(size_t)(it + nb)] == c) nb++;
+            const double *g = host.data() + (size_t)it * IS_B;    // lags have[c] .. have[c] + nb*64
+            const long lag_first = have[(size_t)c];
             bool fin = false;
-            for (long q = 0; q < (long)nlb * IS_B / 2 && !fin; q++) {
+            for (long q = 0; q < nb * IS_B / 2 && !fin; q++) {
                 const long i = lag_first / 2 + q;
                 if (i >= half) { done[(size_t)c] = half; fin = true; break; }
                 const double gam1 = g[2 * q] / len, gam2 = g[2 * q + 1] / len;    // initseq.c:30,39
@@ -186,11 +274,11 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
                     if (i + 1 >= half) { done[(size_t)c] = half; fin = true; }
                 }
             }
+            have[(size_t)c] += nb * IS_B;
+            it += nb;
             if (!fin) next.push_back(c);
         }
         active.swap(next);
-        lag_first += (long)nlb * IS_B;
-        nlb = NLB_MAX;
     }
     bool overflow = false;
     for (long c = 0; c < ncol; c++) {

@@ -125,10 +125,81 @@ def c5(n=4_000_000, p=32, blens=(1000,)):
     return res
 
 
+def c5dev(n=100_000_000, p=256, blen=10000):
+    """BASELINE.json config 5 at full size: p AR(1) columns of n steps generated ON THE DEVICE (column-major
+    n x p, 204.8 GB at the defaults), rho_j = 0.5 + 0.49 j/(p-1).  Generation: blocks of 512 steps by a scaled
+    cumulative sum, carries from the two preceding blocks (rho^1024 < 4e-5: the rest is dropped)."""
+    import torch
+    api.init()
+    L = api.load_library()
+    dev = torch.device("cuda", 0)
+    B = 512
+    assert n % B == 0
+    x = torch.empty((p, n), dtype=torch.float64, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    s_idx = torch.arange(B, dtype=torch.float64, device=dev)
+    t0 = time.perf_counter()
+    for c in range(p):
+        rho = 0.5 + 0.49 * c / max(p - 1, 1)
+        e = torch.randn((n // B, B), dtype=torch.float64, device=dev, generator=g)
+        w = rho ** s_idx                                   # rho^s
+        loc = torch.cumsum(e / w, dim=1) * w               # sum_{s<=t} rho^(t-s) e_s inside a block
+        last = loc[:, -1].clone()
+        carry = torch.zeros_like(last)
+        carry[1:] = last[:-1]
+        carry[2:] += (rho ** B) * last[:-2]
+        loc += carry[:, None] * (rho * w)[None, :]
+        x[c] = loc.reshape(-1)
+        del e, loc
+    x -= x.mean(dim=1, keepdim=True)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    res = []
+    cap = 8192
+    n_out = np.zeros(p, dtype=np.int64)
+    g0, vp, vd, vc = (np.empty(p) for _ in range(4))
+    Gp, Gd, Gc = (np.empty((p, cap)) for _ in range(3))
+    t0 = time.perf_counter()
+    rc = L.mcmchip_initseq(x.data_ptr(), n, p, 1, cap, n_out.ctypes.data, g0.ctypes.data, Gp.ctypes.data,
+                           Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data, vd.ctypes.data, vc.ctypes.data)
+    el = time.perf_counter() - t0
+    assert rc == 0, L.mcmchip_last_error()
+    kn, kms, klaunch = api.last_kernel_time()
+    lags = 2 * n_out
+    res.append({"config": "C5 initseq n=%d p=%d (generated on device, %.1f s)" % (n, p, gen_s), "seconds": el,
+                "kernel": kn, "kernel_ms_avg": kms, "kernel_launches": klaunch, "max_lag_pairs": int(n_out.max()),
+                "mean_lag_pairs": float(n_out.mean()),
+                "useful_lag_products_per_s": float((lags * n).sum() / el),
+                "useful_TFLOPs": float(2.0 * (lags * n).sum() / el / 1e12),
+                "var_con_over_gamma0": [float(v) for v in (vc / g0)[[0, p // 2, p - 1]]],
+                "theory_(1+rho)/(1-rho)": [(1 + r) / (1 - r) for r in (0.5, 0.5 + 0.49 * (p // 2) / max(p - 1, 1), 0.99)]})
+    mean = np.zeros(p)
+    var = np.empty((p, p))
+    for nocalc in (0, 1):
+        t0 = time.perf_counter()
+        rc = L.mcmchip_olbm(x.data_ptr(), n, p, blen, mean.ctypes.data, var.ctypes.data, nocalc, 1)
+        el = time.perf_counter() - t0
+        assert rc == 0, L.mcmchip_last_error()
+        kn, kms, _ = api.last_kernel_time()
+        nf = (p + 15) // 16
+        flops = 2.0 * n * 256.0 * (136 if p > 128 else (36 if p > 64 else 10))
+        res.append({"config": "C5 olbm n=%d p=%d len=%d nocalc=%d" % (n, p, blen, nocalc), "seconds": el,
+                    "kernel": kn, "kernel_ms": kms, "algorithmic_GBps": 8.0 * n * p / (kms * 1e-3) / 1e9,
+                    "executed_TFLOPs": flops / (kms * 1e-3) / 1e12,
+                    "useful_TFLOPs": n * float(p) * (p + 1) / (kms * 1e-3) / 1e12,
+                    "var_diag_over_theory": [float(var[c, c] * n / ((1 / (1 - r * r)) * (1 + r) / (1 - r))) for c, r in
+                                              ((0, 0.5), (p - 1, 0.99))]})
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c4", "c5"]
     for w in which:
-        if w.startswith("c5="):            # c5=n,p,len[,len...]
+        if w.startswith("c5dev"):          # c5dev or c5dev=n,p,len
+            a = [int(v) for v in w[6:].split(",")] if "=" in w else []
+            r = c5dev(*a)
+        elif w.startswith("c5="):            # c5=n,p,len[,len...]
             a = [int(v) for v in w[3:].split(",")]
             r = c5(a[0], a[1], tuple(a[2:]))
         else:
