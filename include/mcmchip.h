@@ -65,8 +65,23 @@ enum {
      *   else -(d+1)log2 - log1p(-(1-bnd_i)^d) */
     MCMCHIP_T_WITCH = 7,
     /* temper only: h(i,x) = beta_i * normmix(x);  par = k, beta[k], then a NORMMIX par block */
-    MCMCHIP_T_TEMPERED_NORMMIX = 8
+    MCMCHIP_T_TEMPERED_NORMMIX = 8,
+    /* the heavy-tailed target of tests/morph.metrop.R:9,13 and devel/reallylong.R:4:
+     * sum_j dt(x_j, df, log=TRUE);  par = df
+     *   = d*(lgamma((df+1)/2) - lgamma(df/2) - log(df*pi)/2) - (df+1)/2 * sum_j log1p(x_j^2/df) */
+    MCMCHIP_T_STUDENT_T = 9
 };
+
+/* variable transformation of morph.metrop() (R/morph.R:121-181, R/morph.metrop.R): the chain runs on the
+ * morphed state y; the log density it sees is lud(inverse(y)) + log.jacobian(y) (morph.R:166-179), the output
+ * functional sees inverse(y) (morph.R:95-106).  inverse(y) = f.inv(|y|) y/|y| + center (isotropic, morph.R:5-14,162)
+ *   EXPO:    f.inv(s) = s <= r ? s : s + (s-r)^p                                   (morph.R:77)
+ *   SUBEXPO: f.inv(s) = s > 1/b ? exp(b s) - e/3 : (s b)^3 e/6 + s b e/2           (morph.R:53-55)
+ *   both:    subexpo.f.inv(expo.f.inv(s))                                          (morph.R:150)
+ * log.jacobian(y) = log f.inv'(|y|) + (d-1)(log f.inv(|y|) - log|y|), d log f.inv'(0) at 0 (morph.R:16-28).
+ * `initial`, `final` and the debug trace of mcmchip_metrop are morphed states; transform() (morph.R:161,
+ * closed form for p = 3, Newton otherwise) runs once on the host. */
+enum { MCMCHIP_MORPH_EXPO = 1, MCMCHIP_MORPH_SUBEXPO = 2, MCMCHIP_MORPH_CENTER = 4 };
 
 typedef struct mcmchip_target_desc {
     int32_t kind;
@@ -77,6 +92,10 @@ typedef struct mcmchip_target_desc {
     double prior_c;     /* logistic kinds: subtract prior_c * sum(beta^2) */
     const double *par;  /* kind-specific parameter block, see enum */
     int64_t npar;
+    int32_t morph_flags;          /* 0: no transformation; else OR of MCMCHIP_MORPH_* (metrop kinds only) */
+    int32_t morph_pad_;
+    double morph_b, morph_r, morph_p;   /* b > 0 (morph.R:51); r >= 0, p > 2 (morph.R:75-76) */
+    const double *morph_center;   /* d doubles (MCMCHIP_MORPH_CENTER), else ignored */
 } mcmchip_target_desc;
 
 typedef struct mcmchip_target mcmchip_target; /* opaque: descriptor resident in HBM */

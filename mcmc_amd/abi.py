@@ -9,6 +9,7 @@ OK, EINVAL, EDOMAIN, EHIP, ECAP = 0, 1, 2, 3, 4
 
 T_LOGISTIC, T_LOGISTIC_NAIVE, T_MVNORM, T_NORMMIX = 1, 2, 3, 4
 T_SIMPLEX, T_BALL, T_WITCH, T_TEMPERED_NORMMIX = 5, 6, 7, 8
+T_STUDENT_T = 9
 TEMPER_KINDS = (T_WITCH, T_TEMPERED_NORMMIX)
 
 SCALE_CONSTANT, SCALE_DIAGONAL, SCALE_FULL, SCALE_LIST = 1, 2, 3, 8
@@ -31,6 +32,12 @@ class TargetDesc(C.Structure):
         ("prior_c", C.c_double),
         ("par", C.c_void_p),
         ("npar", C.c_int64),
+        ("morph_flags", C.c_int32),
+        ("morph_pad_", C.c_int32),
+        ("morph_b", C.c_double),
+        ("morph_r", C.c_double),
+        ("morph_p", C.c_double),
+        ("morph_center", C.c_void_p),
     ]
 
 
@@ -158,8 +165,9 @@ def _f64(a):
 class HostTarget:
     """A log-density descriptor held in host memory (numpy) plus its C struct."""
 
-    def __init__(self, kind, d, x=None, y=None, prior_c=0.0, par=None):
+    def __init__(self, kind, d, x=None, y=None, prior_c=0.0, par=None, morph=None):
         self.kind, self.d = int(kind), int(d)
+        self.morph = morph
         self.x, self.y, self.par = _f64(x), _f64(y), _f64(par)
         self.prior_c = float(prior_c)
         self.n = 0 if self.x is None else self.x.shape[0]
@@ -171,6 +179,13 @@ class HostTarget:
         self.desc = TargetDesc(self.kind, self.d, self.n, np_ptr(self.x), np_ptr(self.y),
                                self.prior_c, np_ptr(self.par),
                                0 if self.par is None else self.par.size)
+        if morph is not None and morph.flags():
+            if self.kind in TEMPER_KINDS:
+                raise ValueError("morph applies to metrop targets only")
+            self.morph_center = morph.center_vector(self.d)
+            self.desc.morph_flags = morph.flags()
+            self.desc.morph_b, self.desc.morph_r, self.desc.morph_p = morph.b, morph.r, morph.p
+            self.desc.morph_center = np_ptr(self.morph_center)
 
     @property
     def is_temper_kind(self):

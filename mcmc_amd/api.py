@@ -95,12 +95,18 @@ def last_kernel_time():
 class Target(abi.HostTarget):
     """Log unnormalised density descriptor, resident in HBM (replaces `obj`/`lud`)."""
 
-    def __init__(self, kind, d, x=None, y=None, prior_c=0.0, par=None, device=None):
-        super().__init__(kind, d, x=x, y=y, prior_c=prior_c, par=par)
+    def __init__(self, kind, d, x=None, y=None, prior_c=0.0, par=None, device=None, morph=None):
+        super().__init__(kind, d, x=x, y=y, prior_c=prior_c, par=par, morph=morph)
+        self._device = device
         init(device)
         h = C.c_void_p()
         _check(load_library().mcmchip_target_create(C.addressof(self.desc), 0, C.byref(h)))
         self.handle = h
+
+    def with_morph(self, morph):
+        """the same descriptor seen through a variable transformation (morph$lud(obj), R/morph.R:166-179)"""
+        return Target(self.kind, self.d, x=self.x, y=self.y, prior_c=self.prior_c, par=self.par,
+                      device=self._device, morph=morph)
 
     def __del__(self):
         try:
@@ -202,6 +208,72 @@ def metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=None, ou
     out["debug"] = bool(debug)
     out["path"] = {abi.PATH_STREAM: "stream", abi.PATH_MFMA: "mfma"}.get(r["path_used"], "?")
     return out
+
+
+def morph_metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=None, outfun=None, debug=None,
+                 morph=None, seed=None, z=None, u=None):
+    """morph.metrop(obj, initial, nbatch, blen = 1, nspac = 1, scale = 1, outfun, debug = FALSE, morph)
+    (R/morph.metrop.R): metrop on the density induced by the change of variable `morph`
+    (mcmc_amd.morph(b, r, p, center)); the chain runs on the morphed state on the device, the descriptor
+    evaluates lud(inverse(y)) + log.jacobian(y) and the output functional sees inverse(y).
+
+    obj   an (unmorphed) Target, or the dict returned by a previous morph_metrop call.
+    Returns metrop's dict plus "morph", "morph.final" (the last morphed state) with "final" = inverse of it
+    and "outfun" = the caller's outfun (R/morph.metrop.R:55-62).
+
+    Reference behaviour kept: the first call does not forward `nspac` (R/morph.metrop.R:42-49), so it runs
+    with nspac = 1 whatever is passed; a restart takes missing arguments from the object (17-21) and starts
+    at obj["morph.final"] (10), or, when a new `morph` is given, at morph.transform(obj["final"]) (14).
+    Deliberate deviation: with a new `morph` on restart the reference keeps sampling obj$lud, the density
+    morphed by the FIRST transformation (metrop.metropolis uses obj$lud), while outfun and final use the new
+    one; here the density is rebuilt with the new transformation as well.
+    """
+    from ._morph import Morph
+    if isinstance(obj, dict):
+        prev = dict(obj)
+        if "morph" not in prev:
+            raise TypeError('argument "obj" must be a Target or the result of morph_metrop')
+        if morph is None:
+            morph = prev["morph"]
+            target = prev["lud"]
+            start = prev["morph.final"]                                  # morph.metrop.R:9-10
+        else:
+            target = prev["base"].with_morph(morph)
+            fin = np.asarray(prev["final"], dtype=np.float64)
+            start = (morph.transform(fin) if fin.ndim == 1
+                     else np.stack([morph.transform(v) for v in fin]))   # morph.metrop.R:14
+        outfun = prev["outfun"] if outfun is None else outfun            # morph.metrop.R:17-21
+        blen = prev["blen"] if blen is None else blen
+        nspac = prev["nspac"] if nspac is None else nspac
+        debug = prev["debug"] if debug is None else debug
+        scale = prev["scale"] if scale is None else scale
+        base = prev["base"]
+        prev["lud"], prev["final"] = target, start
+        if initial is not None:
+            prev["final"] = initial
+        res = metrop(prev, nbatch=nbatch, blen=blen, nspac=nspac, scale=scale, outfun=outfun, debug=debug,
+                     seed=seed, z=z, u=u, path=abi.PATH_STREAM)
+    else:
+        if not isinstance(obj, Target):
+            raise TypeError('argument "obj" must be a Target or the result of morph_metrop')
+        if morph is None:
+            morph = Morph()                                              # morph.identity(), morph.metrop.R:39
+        if initial is None or nbatch is None:
+            raise ValueError('argument "initial"/"nbatch" missing')
+        base = obj
+        target = obj.with_morph(morph)
+        ini = np.asarray(initial, dtype=np.float64)
+        start = morph.transform(ini) if ini.ndim == 1 else np.stack([morph.transform(v) for v in ini])
+        # nspac is not forwarded on the first call (morph.metrop.R:42-49)
+        res = metrop(target, start, nbatch, blen=blen, nspac=None, scale=scale, outfun=outfun, debug=debug,
+                     seed=seed, z=z, u=u, path=abi.PATH_STREAM)
+    mf = np.asarray(res["final"], dtype=np.float64)                       # .morph.unmorph, morph.metrop.R:55-62
+    res["morph"] = morph
+    res["morph.final"] = mf
+    res["final"] = morph.inverse(mf) if mf.ndim == 1 else np.stack([morph.inverse(v) for v in mf])
+    res["outfun"] = outfun
+    res["base"] = base
+    return res
 
 
 def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None, scale=None, outfun=None,

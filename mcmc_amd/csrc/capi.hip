@@ -131,7 +131,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
     if (!desc || !out) return set_error(MCMCHIP_EINVAL, "null argument");
     DeviceCtx *dc = cur_dev();
     if (!dc) return MCMCHIP_EHIP;
-    if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_TEMPERED_NORMMIX)
+    if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_STUDENT_T)
         return set_error(MCMCHIP_EINVAL, "unknown log density descriptor kind %d", desc->kind);
     if (desc->d <= 0) return set_error(MCMCHIP_EINVAL, "descriptor dimension must be positive");
     mcmchip_target *t = new mcmchip_target();
@@ -179,6 +179,22 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             rc = set_error(MCMCHIP_EINVAL, "descriptor kind %d needs a parameter block", desc->kind);
             break;
         }
+        if (desc->kind == MCMCHIP_T_STUDENT_T && !(t->host_par[0] > 0)) { rc = set_error(MCMCHIP_EINVAL, "Student t descriptor needs df > 0"); break; }
+        if (desc->morph_flags) {
+            // morph() argument rules (R/morph.R:51,75-76)
+            if (desc->morph_flags & ~(MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO | MCMCHIP_MORPH_CENTER)) { rc = set_error(MCMCHIP_EINVAL, "unknown morph flags %d", desc->morph_flags); break; }
+            if (is_temper_kind(desc->kind)) { rc = set_error(MCMCHIP_EINVAL, "morph applies to metrop targets only"); break; }
+            if ((desc->morph_flags & MCMCHIP_MORPH_SUBEXPO) && !(desc->morph_b > 0)) { rc = set_error(MCMCHIP_EINVAL, "b > 0 is not TRUE"); break; }
+            if ((desc->morph_flags & MCMCHIP_MORPH_EXPO) && !(desc->morph_p > 2)) { rc = set_error(MCMCHIP_EINVAL, "p > 2 is not TRUE"); break; }
+            if ((desc->morph_flags & MCMCHIP_MORPH_EXPO) && !(desc->morph_r >= 0)) { rc = set_error(MCMCHIP_EINVAL, "r >= 0 is not TRUE"); break; }
+            t->morph_flags = desc->morph_flags;
+            t->morph_b = desc->morph_b; t->morph_r = desc->morph_r; t->morph_p = desc->morph_p;
+            if (desc->morph_flags & MCMCHIP_MORPH_CENTER) {
+                if (!desc->morph_center) { rc = set_error(MCMCHIP_EINVAL, "morph center flagged but null"); break; }
+                if (hipMalloc((void **)&t->morph_center, (size_t)desc->d * 8) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc failed"); break; }
+                if (hipMemcpyAsync(t->morph_center, desc->morph_center, (size_t)desc->d * 8, kind, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of the morph centre failed"); break; }
+            }
+        }
         if (hipStreamSynchronize(dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "stream synchronize failed"); break; }
     } while (0);
     if (rc) { mcmchip_target_destroy(t); return rc; }
@@ -194,6 +210,7 @@ void mcmchip_target_destroy(mcmchip_target *t)
     if (t->par) (void)hipFree(t->par);
     if (t->xt) (void)hipFree(t->xt);
     if (t->colsum) (void)hipFree(t->colsum);
+    if (t->morph_center) (void)hipFree(t->morph_center);
     delete t;
 }
 
@@ -221,7 +238,8 @@ int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchai
     OutBuf ob;
     HIP_TRY(in.set(states, (size_t)nchain * w * 8, device_ptrs, dc->stream));
     HIP_TRY(ob.set(out, (size_t)nchain * 8, device_ptrs));
-    bool mfma = (path == MCMCHIP_PATH_MFMA) || (path == MCMCHIP_PATH_AUTO && t->xt && t->n >= 4096 && nchain >= 64);
+    if (path == MCMCHIP_PATH_MFMA && t->morph_flags) return set_error(MCMCHIP_EINVAL, "the MFMA path does not take a morphed descriptor");
+    bool mfma = (path == MCMCHIP_PATH_MFMA) || (path == MCMCHIP_PATH_AUTO && t->xt && !t->morph_flags && t->n >= 4096 && nchain >= 64);
     int rc;
     if (mfma) rc = launch_logdens_mfma(t, in.as<double>(), nchain, ob.as<double>(), dc);
     else rc = launch_logdens_stream(t, in.as<double>(), nchain, ob.as<double>(), dc->stream);
@@ -287,7 +305,7 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
         return set_error(MCMCHIP_EINVAL, "debug requested but trace outputs are NULL");
     if (!o->accept || !o->batch || !o->final || !o->accept_batch) return set_error(MCMCHIP_EINVAL, "null output");
 
-    bool mfma_ok = t->xt && !a->debug;
+    bool mfma_ok = t->xt && !a->debug && !t->morph_flags;
     bool mfma = (a->path == MCMCHIP_PATH_MFMA) || (a->path == MCMCHIP_PATH_AUTO && mfma_ok && t->n >= 4096 && nchain >= 64);
     if (mfma && !mfma_ok) return set_error(MCMCHIP_EINVAL, "MFMA path needs a logistic descriptor with d <= %d and debug = FALSE", MCMCHIP_MFMA_MAXD);
 
@@ -320,6 +338,8 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
     memset(&p, 0, sizeof p);
     p.kind = t->kind; p.d = d; p.n = t->n; p.x = t->x; p.y = t->y; p.par = t->par; p.npar = t->npar;
     p.prior_c = t->prior_c;
+    p.morph_flags = t->morph_flags; p.morph_b = t->morph_b; p.morph_r = t->morph_r; p.morph_p = t->morph_p;
+    p.morph_center = t->morph_center;
     p.nchain = nchain; p.nbatch = a->nbatch; p.blen = a->blen; p.nspac = a->nspac;
     p.scale_kind = a->scale_kind; p.scale = scale.as<double>();
     p.nout = nout; p.sq_from = sq_from; p.out_map = outmap.as<int>();

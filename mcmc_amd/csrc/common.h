@@ -135,6 +135,10 @@ struct mcmchip_target {
     double *par = nullptr;
     int64_t npar = 0;
     std::vector<double> host_par;
+    // morph (R/morph.R): flags, shape parameters, centre (d doubles in HBM or null)
+    int morph_flags = 0;
+    double morph_b = 1, morph_r = 0, morph_p = 3;
+    double *morph_center = nullptr;
     // fp64 MFMA layout (logistic kind only): sign-folded, zero-padded, fragment-major tiles
     int dpad = 0, ksteps = 0;
     int64_t ntiles = 0;     // 16-observation tiles (padded up to a multiple of MFMA_TILES_PER_CHUNK)

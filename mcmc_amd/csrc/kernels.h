@@ -10,6 +10,9 @@ struct MetropDev {
     const double *x, *y, *par;
     long npar;
     double prior_c;
+    int morph_flags;          // morph.metrop: the chain runs on the morphed state (R/morph.R:121-181)
+    double morph_b, morph_r, morph_p;
+    const double *morph_center;
     // run shape
     long nchain;
     int nbatch, blen, nspac;

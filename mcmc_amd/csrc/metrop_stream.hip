@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
 
     TargetView tv;
     tv.kind = p.kind; tv.d = d; tv.n = p.n; tv.par = p.par; tv.prior_c = p.prior_c;
+    tv.morph_flags = p.morph_flags; tv.morph_b = p.morph_b; tv.morph_r = p.morph_r; tv.morph_p = p.morph_p;
+    tv.morph_center = p.morph_center;
     double *base = lds;
     if (lay.x_in_lds) {
         double *xs = lds, *ys = lds + p.n * d;
@@ -54,10 +56,11 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
     double *Y = X + d;                                 // proposal
     double *Z = Y + d;                                 // normals
     double *B = Z + d;                                 // batch accumulator
+    double *W = B + nout;                              // morph only: inverse(state), what lud and outfun see
     for (int j = g; j < d; j += G) X[j] = p.initial[(size_t)chain * d + j];
     __syncthreads();
 
-    double cur = lud_group<G>(tv, X, g);
+    double cur = lud_morphed_group<G>(tv, X, W, g);
     if (live && g == 0) {
         if (cur == -INFINITY) atomicOr(p.flag, FLAG_NEGINF_INIT);
         else if (cur == INFINITY) atomicOr(p.flag, FLAG_POSINF);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
                 }
                 __syncthreads();
                 // ---- log density of the proposal (logh(), metrop.c:223)
-                const double ly = lud_group<G>(tv, Y, g);
+                const double ly = lud_morphed_group<G>(tv, Y, W, g);
                 if (ly == INFINITY || isnan(ly)) {
                     if (live && g == 0) atomicOr(p.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF);
                 }
@@ -144,8 +147,13 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
                 __syncthreads();
             }
             // ---- outfun + batch accumulation, once per blen step (metrop.c:273-275)
+            const double *S = X;
+            if (p.morph_flags) {                        // morph$outfun: g(inverse(state)), morph.R:95-106
+                morph_inverse_group<G>(tv, X, W, g);
+                S = W;
+            }
             for (int k = g; k < nout; k += G) {
-                double v = X[p.out_map[k]];
+                double v = S[p.out_map[k]];
                 if (k >= p.sq_from) v = mul_nofma(v, v);
                 B[k] = add_nofma(B[k], v);
             }
@@ -178,9 +186,10 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
     long work = d;
     if (p.kind == MCMCHIP_T_LOGISTIC || p.kind == MCMCHIP_T_LOGISTIC_NAIVE) work = p.n;
     else if (p.kind == MCMCHIP_T_NORMMIX) work = 8;
+    else if (p.morph_flags && d <= 16) work = 1;   // small morphed targets: one lane per chain keeps the norm's summation order
     int G = pick_group(work, p.nchain);
     StreamLayout lay;
-    lay.per_chain = 3 * d + p.nout;
+    lay.per_chain = 3 * d + p.nout + (p.morph_flags ? d : 0);
     const size_t budget = 64 * 1024;
     size_t xbytes = (p.x ? (size_t)(p.n * d + p.n) * 8 : 0);
     for (;;) {
@@ -212,6 +221,7 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
 __global__ __launch_bounds__(256) void logdens_stream_kernel(TargetView tv, int temper_kind, long ncomp_l,
                                                              const double *states, long nchain, double *out)
 {
+    extern __shared__ double ld_w[];      // morph only: 16 x d doubles
     constexpr int G = 16;
     const int g = threadIdx.x % G;
     const int ncomp = (int)ncomp_l;
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256) void logdens_stream_kernel(TargetView tv, int 
         const double *s = states + (size_t)c * (tv.d + 1);
         v = lud_temper(tv.kind, tv.d, tv.par, ncomp, (int)s[0], s + 1);
     } else {
-        v = lud_group<G>(tv, states + (size_t)c * tv.d, g);
+        v = lud_morphed_group<G>(tv, states + (size_t)c * tv.d, ld_w + (size_t)(threadIdx.x / G) * tv.d, g);
     }
     if (live && g == 0) out[c] = v;
 }
@@ -234,9 +244,13 @@ int launch_logdens_stream(const mcmchip_target *t, const double *states, long nc
     TargetView tv;
     tv.kind = t->kind; tv.d = t->d; tv.n = t->n; tv.x = t->x; tv.y = t->y; tv.par = t->par;
     tv.prior_c = t->prior_c;
+    tv.morph_flags = t->morph_flags; tv.morph_b = t->morph_b; tv.morph_r = t->morph_r; tv.morph_p = t->morph_p;
+    tv.morph_center = t->morph_center;
+    const size_t wbytes = t->morph_flags ? (size_t)16 * t->d * 8 : 0;
+    if (wbytes > 64 * 1024) return set_error(MCMCHIP_EINVAL, "state dimension %d too large for a morphed log density", t->d);
     int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX);
     dim3 grid((unsigned)((nchain + 15) / 16)), block(256);
-    hipLaunchKernelGGL(logdens_stream_kernel, grid, block, 0, s, tv, temper_kind,
+    hipLaunchKernelGGL(logdens_stream_kernel, grid, block, wbytes, s, tv, temper_kind,
                        (long)(t->kind == MCMCHIP_T_WITCH ? t->npar : 0), states, nchain, out);
     HIP_TRY(hipGetLastError());
     return MCMCHIP_OK;

@@ -16,6 +16,9 @@ struct TargetView {
     const double *x, *y;   // may point into LDS
     const double *par;
     double prior_c;
+    int morph_flags;
+    double morph_b, morph_r, morph_p;
+    const double *morph_center;
 };
 
 template <int G> __device__ __forceinline__ double group_sum(double v)
@@ -137,9 +140,92 @@ template <int G> __device__ double lud_group(const TargetView &t, const double *
         double fred = 1.0 - s;
         return (fred > 0) ? log(fred) : -INFINITY;
     }
+    case MCMCHIP_T_STUDENT_T: {
+        // tests/morph.metrop.R:9: sum_j dt(x_j, df, log=TRUE)
+        const double df = t.par[0];
+        double s = 0.0;
+        for (int j = g; j < d; j += G) s += log1p(v[j] * v[j] / df);
+        s = group_sum<G>(s);
+        return d * (lgamma((df + 1) / 2) - lgamma(df / 2) - 0.5 * log(df * M_PI)) - (df + 1) / 2 * s;
+    }
     default:
         return NAN;
     }
+}
+
+// ---- morph (R/morph.R): f.inv and its derivative at a norm, the isotropic inverse and log.jacobian ----
+__device__ inline double morph_expo_finv(const TargetView &t, double x)      // morph.R:77
+{
+    return x <= t.morph_r ? x : x + pow(x - t.morph_r, t.morph_p);
+}
+__device__ inline double morph_expo_dfinv(const TargetView &t, double x)     // morph.R:78
+{
+    return x <= t.morph_r ? 1.0 : 1.0 + t.morph_p * pow(x - t.morph_r, t.morph_p - 1.0);
+}
+__device__ inline double morph_sub_finv(const TargetView &t, double x)       // morph.R:53-55
+{
+    const double b = t.morph_b, e1 = 2.718281828459045;
+    return x > 1 / b ? exp(b * x) - e1 / 3 : pow(x * b, 3.0) * e1 / 6 + x * b * e1 / 2;
+}
+__device__ inline double morph_sub_dfinv(const TargetView &t, double x)      // morph.R:56-58
+{
+    const double b = t.morph_b, e1 = 2.718281828459045;
+    return x > 1 / b ? b * exp(b * x) : b * ((x * b) * (x * b)) * e1 / 2 + b * e1 / 2;
+}
+__device__ inline double morph_finv(const TargetView &t, double x)           // morph.R:133-152
+{
+    const bool ex = t.morph_flags & MCMCHIP_MORPH_EXPO, su = t.morph_flags & MCMCHIP_MORPH_SUBEXPO;
+    if (ex && su) return morph_sub_finv(t, morph_expo_finv(t, x));
+    if (ex) return morph_expo_finv(t, x);
+    if (su) return morph_sub_finv(t, x);
+    return x;
+}
+__device__ inline double morph_dfinv(const TargetView &t, double x)
+{
+    const bool ex = t.morph_flags & MCMCHIP_MORPH_EXPO, su = t.morph_flags & MCMCHIP_MORPH_SUBEXPO;
+    if (ex && su) return morph_expo_dfinv(t, x) * morph_sub_dfinv(t, morph_expo_finv(t, x));
+    if (ex) return morph_expo_dfinv(t, x);
+    if (su) return morph_sub_dfinv(t, x);
+    return 1.0;
+}
+
+// w = inverse(y) = f.inv(|y|) y/|y| + center (morph.R:5-14,162), written by the chain's G lanes into w (LDS,
+// same wavefront: no barrier needed); returns |y|
+template <int G> __device__ double morph_inverse_group(const TargetView &t, const double *y, double *w, int g)
+{
+    const int d = t.d;
+    const bool shaped = t.morph_flags & (MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO);
+    double nrm = 0.0, fac = 1.0;
+    if (shaped) {
+        double ss = 0.0;
+        if (G == 1) { for (int j = 0; j < d; j++) ss += y[j] * y[j]; }       // the reference's summation order
+        else { for (int j = g; j < d; j += G) ss += y[j] * y[j]; ss = group_sum<G>(ss); }
+        nrm = sqrt(ss);
+    }
+    const double fi = (shaped && nrm != 0) ? morph_finv(t, nrm) : 0.0;
+    for (int j = g; j < d; j += G) {
+        double v = y[j];
+        if (shaped) v = (nrm == 0) ? 0.0 : fi * y[j] / nrm;
+        if (t.morph_flags & MCMCHIP_MORPH_CENTER) v += t.morph_center[j];
+        w[j] = v;
+    }
+    return nrm;
+}
+
+// what logh() sees under morph.metrop (morph.R:166-179): lud(inverse(y)) + log.jacobian(y); -Inf, NaN and +Inf of
+// the descriptor pass through unchanged for the caller's checks
+template <int G> __device__ double lud_morphed_group(const TargetView &t, const double *y, double *w, int g)
+{
+    if (!t.morph_flags) return lud_group<G>(t, y, g);
+    const double nrm = morph_inverse_group<G>(t, y, w, g);
+    const double foo = lud_group<G>(t, w, g);
+    if (foo == -INFINITY || isnan(foo) || foo == INFINITY) return foo;
+    if (!(t.morph_flags & (MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO))) return foo;      // morph.R:131
+    const int d = t.d;
+    double lj;
+    if (nrm == 0) lj = d * log(morph_dfinv(t, nrm));                                       // morph.R:22-23
+    else lj = log(morph_dfinv(t, nrm)) + (d - 1) * (log(morph_finv(t, nrm)) - log(nrm));   // morph.R:25
+    return foo + lj;
 }
 
 // temper targets; state = (i, theta[p]) with 1-based component i.  Small p: every lane of the

@@ -66,6 +66,13 @@ def lib():
         L.orc_initseq.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 7
         L.orc_olbm.restype = C.c_int
         L.orc_olbm.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        for nm in ("orc_morph_f", "orc_morph_finv", "orc_morph_dfinv"):
+            getattr(L, nm).restype = C.c_double
+            getattr(L, nm).argtypes = [C.c_void_p, C.c_double]
+        L.orc_morph_inverse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_morph_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_morph_logjac.restype = C.c_double
+        L.orc_morph_logjac.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -122,6 +129,31 @@ def logdens(target, states):
     out = np.empty(s.shape[0])
     lib().orc_logdens(C.addressof(target.desc), s.ctypes.data, s.shape[0], out.ctypes.data)
     return out
+
+
+def morph_scalar(target, which, x):
+    """f / f.inv / d.f.inv of the target's morph (R/morph.R:49-93,133-152) at a scalar"""
+    fn = {"f": lib().orc_morph_f, "f.inv": lib().orc_morph_finv, "d.f.inv": lib().orc_morph_dfinv}[which]
+    return fn(C.addressof(target.desc), float(x))
+
+
+def morph_inverse(target, state):
+    y = np.ascontiguousarray(state, dtype=np.float64)
+    out = np.empty_like(y)
+    lib().orc_morph_inverse(C.addressof(target.desc), y.ctypes.data, out.ctypes.data)
+    return out
+
+
+def morph_transform(target, state):
+    x = np.ascontiguousarray(state, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_morph_transform(C.addressof(target.desc), x.ctypes.data, out.ctypes.data)
+    return out
+
+
+def morph_logjac(target, state):
+    y = np.ascontiguousarray(state, dtype=np.float64)
+    return lib().orc_morph_logjac(C.addressof(target.desc), y.ctypes.data)
 
 
 def metrop(target, initial, nbatch, blen=1, nspac=1, scale=1.0, outfun=None, debug=False,

@@ -117,7 +117,7 @@ static double normmix_eval(const double *par, int d, const double *x)
 }
 
 /* metrop targets: state = x[d] */
-double orc_lud(const mcmchip_target_desc *t, const double *b)
+static double lud_base(const mcmchip_target_desc *t, const double *b)
 {
     int d = t->d;
     switch (t->kind) {
@@ -182,9 +182,133 @@ double orc_lud(const mcmchip_target_desc *t, const double *b)
         double fred = 1.0 - (double)s;
         return (fred > 0) ? log(fred) : -INFINITY;
     }
+    case MCMCHIP_T_STUDENT_T: {
+        /* tests/morph.metrop.R:9 dt(x, df, log=TRUE), summed over coordinates.  R's dt() itself (Rmath,
+         * not under /root/reference) uses Loader's saddle-point form; this is the textbook density */
+        double df = t->par[0], s = 0.0;
+        for (int j = 0; j < d; j++) s += log1p(b[j] * b[j] / df);
+        return d * (lgamma((df + 1) / 2) - lgamma(df / 2) - 0.5 * log(df * M_PI)) - (df + 1) / 2 * s;
+    }
     default:
         return NAN;
     }
+}
+
+/* ------------------------------------------------------------------ */
+/* morph (R/morph.R)                                                    */
+/* ------------------------------------------------------------------ */
+static double expo_finv(const mcmchip_target_desc *t, double x)     /* morph.R:77 */
+{
+    return x <= t->morph_r ? x : x + pow(x - t->morph_r, t->morph_p);
+}
+static double expo_dfinv(const mcmchip_target_desc *t, double x)    /* morph.R:78 */
+{
+    return x <= t->morph_r ? 1.0 : 1.0 + t->morph_p * pow(x - t->morph_r, t->morph_p - 1.0);
+}
+static double sub_finv(const mcmchip_target_desc *t, double x)      /* morph.R:53-55 */
+{
+    double b = t->morph_b, e1 = exp(1.0);
+    return x > 1 / b ? exp(b * x) - e1 / 3 : pow(x * b, 3.0) * e1 / 6 + x * b * e1 / 2;   /* R's ^: pow() unless the exponent is 2 */
+}
+static double sub_dfinv(const mcmchip_target_desc *t, double x)     /* morph.R:56-58 */
+{
+    double b = t->morph_b, e1 = exp(1.0);
+    return x > 1 / b ? b * exp(b * x) : b * ((x * b) * (x * b)) * e1 / 2 + b * e1 / 2;
+}
+double orc_morph_finv(const mcmchip_target_desc *t, double x)       /* morph.R:133-152 */
+{
+    int ex = t->morph_flags & MCMCHIP_MORPH_EXPO, su = t->morph_flags & MCMCHIP_MORPH_SUBEXPO;
+    if (ex && su) return sub_finv(t, expo_finv(t, x));
+    if (ex) return expo_finv(t, x);
+    if (su) return sub_finv(t, x);
+    return x;
+}
+double orc_morph_dfinv(const mcmchip_target_desc *t, double x)
+{
+    int ex = t->morph_flags & MCMCHIP_MORPH_EXPO, su = t->morph_flags & MCMCHIP_MORPH_SUBEXPO;
+    if (ex && su) return expo_dfinv(t, x) * sub_dfinv(t, expo_finv(t, x));
+    if (ex) return expo_dfinv(t, x);
+    if (su) return sub_dfinv(t, x);
+    return 1.0;
+}
+static double expo_f(const mcmchip_target_desc *t, double x)        /* morph.R:79-91 */
+{
+    double r = t->morph_r, p = t->morph_p;
+    if (x < r) return x;
+    if (p == 3) {
+        double n = sqrt((27 * r - 27 * x) * (27 * r - 27 * x) + 108) + 27 * (r - x);
+        return r + pow(2 / n, 1.0 / 3) - pow(n / 2, 1.0 / 3) / 3;
+    }
+    /* newton.raphson (morph.R:35-47) from x0 = r + x^(1/p) */
+    double x0 = r + pow(x, 1 / p), err = expo_finv(t, x0) - x;
+    while (err >= sqrt(2.220446049250313e-16)) {
+        x0 -= err / expo_dfinv(t, x0);
+        err = expo_finv(t, x0) - x;
+    }
+    return x0 - err / expo_dfinv(t, x0);
+}
+static double sub_f(const mcmchip_target_desc *t, double x)         /* morph.R:59-68 */
+{
+    double b = t->morph_b, e1 = exp(1.0);
+    if (x > 2 * e1 / 3) return log(x + e1 / 3) / b;
+    double pi_ = exp(1.0 / 3) * pow(sqrt(pow(b, 12) * (9 * x * x + exp(2.0))) - 3 * pow(b, 6) * x, -1.0 / 3);
+    return pi_ * b - 1 / (pi_ * pow(b, 3));
+}
+double orc_morph_f(const mcmchip_target_desc *t, double x)          /* morph.R:136,142,149 */
+{
+    int ex = t->morph_flags & MCMCHIP_MORPH_EXPO, su = t->morph_flags & MCMCHIP_MORPH_SUBEXPO;
+    if (ex && su) return expo_f(t, sub_f(t, x));
+    if (ex) return expo_f(t, x);
+    if (su) return sub_f(t, x);
+    return x;
+}
+static double enorm(const double *x, int d)                         /* morph.R:1-3 */
+{
+    double s = 0.0;
+    for (int j = 0; j < d; j++) s += x[j] * x[j];
+    return sqrt(s);
+}
+/* inverse(state) = f.inv(state) + center, f.inv isotropic (morph.R:5-14,155,162) */
+void orc_morph_inverse(const mcmchip_target_desc *t, const double *y, double *x)
+{
+    int d = t->d;
+    int shaped = t->morph_flags & (MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO);
+    double nrm = shaped ? enorm(y, d) : 0.0;
+    for (int j = 0; j < d; j++) {
+        double v = y[j];
+        if (shaped) v = (nrm == 0) ? 0.0 : orc_morph_finv(t, nrm) * y[j] / nrm;
+        if (t->morph_flags & MCMCHIP_MORPH_CENTER) v += t->morph_center[j];
+        x[j] = v;
+    }
+}
+/* transform(state) = f(state - center) (morph.R:161) */
+void orc_morph_transform(const mcmchip_target_desc *t, const double *x, double *y)
+{
+    int d = t->d;
+    double c[d];
+    for (int j = 0; j < d; j++) c[j] = x[j] - ((t->morph_flags & MCMCHIP_MORPH_CENTER) ? t->morph_center[j] : 0.0);
+    int shaped = t->morph_flags & (MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO);
+    double nrm = shaped ? enorm(c, d) : 0.0;
+    for (int j = 0; j < d; j++) y[j] = !shaped ? c[j] : (nrm == 0 ? 0.0 : orc_morph_f(t, nrm) * c[j] / nrm);
+}
+double orc_morph_logjac(const mcmchip_target_desc *t, const double *y)   /* morph.R:16-28,131 */
+{
+    int d = t->d;
+    if (!(t->morph_flags & (MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO))) return 0.0;
+    double nrm = enorm(y, d);
+    if (nrm == 0) return d * log(orc_morph_dfinv(t, nrm));
+    return log(orc_morph_dfinv(t, nrm)) + (d - 1) * (log(orc_morph_finv(t, nrm)) - log(nrm));
+}
+
+/* what metrop's logh() evaluates: the descriptor, seen through the morph if there is one (morph.R:166-179) */
+double orc_lud(const mcmchip_target_desc *t, const double *b)
+{
+    if (!t->morph_flags) return lud_base(t, b);
+    double x[t->d];
+    orc_morph_inverse(t, b, x);
+    double foo = lud_base(t, x);
+    if (foo == -INFINITY || isnan(foo) || foo == INFINITY) return foo;
+    return foo + orc_morph_logjac(t, b);
 }
 
 /* temper targets: state = (i, theta[d]), i is 1-based */
@@ -355,7 +479,13 @@ static int metrop_chain(const mcmchip_target_desc *t, const mcmchip_metrop_args 
                 }
                 tries++; tries_b++;
             }
-            apply_out(a->out_kind, a->out_index, d, x, g);
+            if (t->morph_flags) {                   /* morph$outfun (morph.R:95-106): g(inverse(state)) */
+                double xi[d];
+                orc_morph_inverse(t, x, xi);
+                apply_out(a->out_kind, a->out_index, d, xi, g);
+            } else {
+                apply_out(a->out_kind, a->out_index, d, x, g);
+            }
             for (int j = 0; j < nout; j++) buf[j] += g[j];
         }
         for (int j = 0; j < nout; j++)

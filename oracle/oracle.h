@@ -31,6 +31,13 @@ void orc_philox_normals(uint64_t seed, uint64_t chain, uint64_t iter, int d, dou
 double orc_philox_uniform(uint64_t seed, uint64_t chain, uint64_t iter);
 
 double orc_lud(const mcmchip_target_desc *t, const double *x);
+/* morph (R/morph.R): scalar maps and the isotropic vector maps around them */
+double orc_morph_f(const mcmchip_target_desc *t, double x);
+double orc_morph_finv(const mcmchip_target_desc *t, double x);
+double orc_morph_dfinv(const mcmchip_target_desc *t, double x);
+void orc_morph_inverse(const mcmchip_target_desc *t, const double *y, double *x);
+void orc_morph_transform(const mcmchip_target_desc *t, const double *x, double *y);
+double orc_morph_logjac(const mcmchip_target_desc *t, const double *y);
 double orc_lud_temper(const mcmchip_target_desc *t, int i, const double *theta);
 void orc_logdens(const mcmchip_target_desc *t, const double *states, int64_t nchain, double *out);
 

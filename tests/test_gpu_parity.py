@@ -553,3 +553,107 @@ def test_temper_debug_trace_checks(api, oracle_mod, parallel):
             assert np.allclose(kept[:, 1:].reshape(nbatch, blen, p).mean(axis=1), o["batch"][e], rtol=1e-14, atol=1e-15)
             ib = np.stack([(kept[:, 0] == c + 1).reshape(nbatch, blen).mean(axis=1) for c in range(k)], axis=1)
             assert np.array_equal(ib, o["ibatch"][e])                                # temp-ser.R:152-161
+
+
+# ----------------------------------------------------------------------------- morph.metrop on the device
+MORPHS = [dict(b=1.0), dict(r=1.0, p=3), dict(b=0.7, r=0.5, p=3), dict(r=0.3, p=2.2),
+          dict(b=1.0, center=[0.5, -1.0, 2.0]), dict(center=[1.0, 2.0, 3.0])]
+
+
+@pytest.mark.parametrize("kw", MORPHS)
+def test_morphed_logdens_vs_oracle(api, oracle_mod, kw):
+    # what logh() sees under morph.metrop: lud(inverse(y)) + log.jacobian(y), R/morph.R:166-179
+    from mcmc_amd import morph
+    rng = np.random.default_rng(11)
+    m = morph(**kw)
+    d = 3
+    states = np.concatenate([rng.standard_normal((200, d)) * 1.5, np.zeros((1, d)), rng.standard_normal((55, d)) * 0.01])
+    for K, par in ((abi.T_STUDENT_T, [3.0]), (abi.T_MVNORM, np.concatenate([[0.3, -0.2, 0.1], np.eye(d).ravel() * 2]))):
+        got = api.logdens(api.Target(K, d, par=par, morph=m), states, path=abi.PATH_STREAM)
+        want = oracle_mod.logdens(oracle_mod.Target(K, d, par=par, morph=m), states)
+        assert np.all(np.isfinite(want))
+        assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)) < 1e-12
+    # unmorphed Student t against scipy's dt
+    from scipy.stats import t as student
+    got = api.logdens(api.Target(abi.T_STUDENT_T, d, par=[3.0]), states, path=abi.PATH_STREAM)
+    assert np.max(np.abs(got - student.logpdf(states, 3.0).sum(axis=1))) < 1e-12
+
+
+@pytest.mark.parametrize("kw", MORPHS)
+@pytest.mark.parametrize("outfun", [None, "moments", [True, False, True]])
+def test_morphed_metrop_trajectory_vs_oracle(api, oracle_mod, kw, outfun):
+    # the chain runs on the morphed state; outfun sees inverse(state) (R/morph.R:95-106)
+    from mcmc_amd import morph
+    rng = np.random.default_rng(12)
+    m = morph(**kw)
+    d, C, nbatch, blen, nspac = 3, 64, 25, 3, 2
+    niter = nbatch * blen * nspac
+    init = rng.standard_normal((C, d))
+    z, u = rng.standard_normal((C, niter, d)), rng.random((C, niter))
+    of = "moments2" if outfun == "moments" else outfun
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_STUDENT_T, d, par=[3.0], morph=m), init, nbatch, blen, nspac,
+                            scale=0.8, outfun=of, z=z, u=u, debug=True)
+    o = api.metrop(api.Target(abi.T_STUDENT_T, d, par=[3.0], morph=m), init, nbatch, blen, nspac, scale=0.8,
+                   outfun=of, z=z, u=u, debug=True)
+    assert np.array_equal(o["debug.accept"], ref["debug_accept"] != 0)
+    assert np.array_equal(np.isnan(o["u"]), np.isnan(ref["u"]))
+    assert np.array_equal(o["final"], ref["final"])
+    assert o["batch"].shape == ref["batch"].shape
+    assert np.max(np.abs(o["batch"] - ref["batch"]) / np.maximum(np.abs(ref["batch"]), 1.0)) < 1e-12
+    assert np.max(np.abs(o["log.green"] - ref["log_green"])) < 1e-11
+    assert 0.05 < o["accept"].mean() < 0.95
+
+
+def test_morph_metrop_api_and_restart(api):
+    # tests/morph.metrop.R:8-18 (runs; the transformation can be changed), tests/saveseedmorph.R (restart
+    # determinism), R/morph.metrop.R:42-49 (nspac is not forwarded on the first call), 55-62 (.morph.unmorph)
+    import mcmc_amd
+    from mcmc_amd import morph
+    tg = api.Target(abi.T_STUDENT_T, 1, par=[3.0])
+    obj = mcmc_amd.morph_metrop(tg, [100.0], 100, morph=morph(b=3), seed=42)
+    assert set(obj) >= {"accept", "batch", "initial", "final", "accept.batch", "morph", "morph.final", "outfun"}
+    assert obj["final"] == pytest.approx(obj["morph"].inverse(obj["morph.final"]))
+    obj = mcmc_amd.morph_metrop(obj, morph=morph(b=1))
+    assert obj["morph"].b == 1.0 and obj["batch"].shape == (100, 1)
+    tg3 = api.Target(abi.T_STUDENT_T, 3, par=[3.0])
+    obj = mcmc_amd.morph_metrop(tg3, np.full(3, 100.0), 100, morph=morph(p=3, b=1), seed=1)
+    obj = mcmc_amd.morph_metrop(obj, morph=morph(r=1, p=3, b=1))
+    assert obj["batch"].shape == (100, 3)
+
+    # saveseedmorph.R with the simplex target of the reference's test
+    h = api.Target(abi.T_SIMPLEX, 5, par=[1.0])
+    out = mcmc_amd.morph_metrop(h, np.zeros(5), 100, blen=17, nspac=3, scale=0.1, seed=42)
+    assert out["nspac"] == 1 and out["blen"] == 17            # the quirk: nspac dropped on the first call
+    out1 = mcmc_amd.morph_metrop(out)
+    out2 = mcmc_amd.morph_metrop(out1)
+    out3 = mcmc_amd.morph_metrop(out, nbatch=2 * out["nbatch"])
+    assert np.array_equal(np.concatenate([out1["batch"], out2["batch"]]), out3["batch"])
+    out = mcmc_amd.morph_metrop(out, morph=morph(p=2.2, r=0.3))
+    out1 = mcmc_amd.morph_metrop(out)
+    out2 = mcmc_amd.morph_metrop(out1)
+    out3 = mcmc_amd.morph_metrop(out, nbatch=2 * out["nbatch"])
+    assert np.array_equal(np.concatenate([out1["batch"], out2["batch"]]), out3["batch"])
+    assert np.all(out3["batch"] >= 0) and np.all(out3["batch"].sum(axis=1) <= 1 + 1e-12)   # outfun sees inverse(state)
+
+
+def test_morph_metrop_samples_the_right_distribution(api):
+    # morphed chains on a heavy-tailed target: the unmorphed draws must follow t_3 (vignettes/morph.Rnw's point)
+    import mcmc_amd
+    from mcmc_amd import morph
+    from scipy.stats import t as student
+    tg = api.Target(abi.T_STUDENT_T, 1, par=[3.0])
+    out = mcmc_amd.morph_metrop(tg, np.zeros((2048, 1)), 400, blen=1, scale=2.0, morph=morph(b=1), seed=7)
+    draws = out["batch"][:, 100:, 0].ravel()
+    q = np.quantile(draws, [0.05, 0.25, 0.5, 0.75, 0.95])
+    assert np.max(np.abs(q - student.ppf([0.05, 0.25, 0.5, 0.75, 0.95], 3.0))) < 0.05
+
+
+def test_morph_descriptor_errors(api):
+    from mcmc_amd import morph
+    with pytest.raises(ValueError, match="metrop targets only"):
+        api.Target(abi.T_WITCH, 2, par=[0.5, 0.25], morph=morph(b=1))
+    X = np.ones((8, 2))
+    y = np.zeros(8)
+    tg = api.Target(abi.T_LOGISTIC, 2, x=X, y=y, prior_c=0.125, morph=morph(b=1))
+    with pytest.raises(api.McmcHipError, match="MFMA path"):
+        api.logdens(tg, np.zeros((4, 2)), path=abi.PATH_MFMA)
