@@ -69,7 +69,16 @@ enum {
     /* the heavy-tailed target of tests/morph.metrop.R:9,13 and devel/reallylong.R:4:
      * sum_j dt(x_j, df, log=TRUE);  par = df
      *   = d*(lgamma((df+1)/2) - lgamma(df/2) - log(df*pi)/2) - (df+1)/2 * sum_j log1p(x_j^2/df) */
-    MCMCHIP_T_STUDENT_T = 9
+    MCMCHIP_T_STUDENT_T = 9,
+    /* temper only, state = (i, beta[d]): the model-selection posterior of tests/temp-par.R:39-56,
+     * tests/temp-ser.R and vignettes/bfst.Rnw:472-489.  x (n x d), y as for LOGISTIC;
+     * par = k, then k x d 0/1 model masks (row-major; column 0 is the intercept), then k log pseudo-priors,
+     * then one additive constant.
+     *   eta = X (beta * mask_i);  logp/logq as LOGISTIC;
+     *   sum(logp[y==1]) + sum(logq[y==0]) - prior_c*sum(beta^2) + constant + log_pseudo_prior[i]
+     * temp-par.R: prior_c = 1/2, constant = 0, pseudo-priors 0;  bfst.Rnw: sum(dnorm(beta, 0, 2, log=TRUE))
+     * = -sum(beta^2)/8 - d*log(2*sqrt(2*pi)), i.e. prior_c = 1/8 and that constant */
+    MCMCHIP_T_LOGISTIC_MODELS = 10
 };
 
 /* variable transformation of morph.metrop() (R/morph.R:121-181, R/morph.metrop.R): the chain runs on the

@@ -10,7 +10,8 @@ OK, EINVAL, EDOMAIN, EHIP, ECAP = 0, 1, 2, 3, 4
 T_LOGISTIC, T_LOGISTIC_NAIVE, T_MVNORM, T_NORMMIX = 1, 2, 3, 4
 T_SIMPLEX, T_BALL, T_WITCH, T_TEMPERED_NORMMIX = 5, 6, 7, 8
 T_STUDENT_T = 9
-TEMPER_KINDS = (T_WITCH, T_TEMPERED_NORMMIX)
+T_LOGISTIC_MODELS = 10
+TEMPER_KINDS = (T_WITCH, T_TEMPERED_NORMMIX, T_LOGISTIC_MODELS)
 
 SCALE_CONSTANT, SCALE_DIAGONAL, SCALE_FULL, SCALE_LIST = 1, 2, 3, 8
 OUT_IDENTITY, OUT_INDEX, OUT_MOMENTS2 = 0, 1, 2
@@ -190,6 +191,17 @@ class HostTarget:
     @property
     def is_temper_kind(self):
         return self.kind in TEMPER_KINDS
+
+
+def logistic_models_par(models, log_pseudo_prior=None, constant=0.0):
+    """parameter block of MCMCHIP_T_LOGISTIC_MODELS: `models` is the k x d 0/1 matrix of which coefficients
+    (intercept included) enter the linear predictor of component i (tests/temp-par.R:12-13,48-50)"""
+    m = np.asarray(models, dtype=np.float64)
+    k = m.shape[0]
+    lpp = np.zeros(k) if log_pseudo_prior is None else np.asarray(log_pseudo_prior, dtype=np.float64)
+    if lpp.shape != (k,):
+        raise ValueError("length(log.pseudo.prior) == nrow(models) is not TRUE")
+    return np.concatenate([[float(k)], m.ravel(), lpp, [float(constant)]])
 
 
 def normmix_par(weights, means, sds):

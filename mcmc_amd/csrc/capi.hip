@@ -122,8 +122,8 @@ int mcmchip_last_kernel_time(double *avg_ms, int64_t *launches, char *name, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-static bool is_logistic(int kind) { return kind == MCMCHIP_T_LOGISTIC || kind == MCMCHIP_T_LOGISTIC_NAIVE; }
-static bool is_temper_kind(int kind) { return kind == MCMCHIP_T_WITCH || kind == MCMCHIP_T_TEMPERED_NORMMIX; }
+static bool is_logistic(int kind) { return kind == MCMCHIP_T_LOGISTIC || kind == MCMCHIP_T_LOGISTIC_NAIVE || kind == MCMCHIP_T_LOGISTIC_MODELS; }
+static bool is_temper_kind(int kind) { return kind == MCMCHIP_T_WITCH || kind == MCMCHIP_T_TEMPERED_NORMMIX || kind == MCMCHIP_T_LOGISTIC_MODELS; }
 
 int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs, mcmchip_target **out)
 {
@@ -131,7 +131,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
     if (!desc || !out) return set_error(MCMCHIP_EINVAL, "null argument");
     DeviceCtx *dc = cur_dev();
     if (!dc) return MCMCHIP_EHIP;
-    if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_STUDENT_T)
+    if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_LOGISTIC_MODELS)
         return set_error(MCMCHIP_EINVAL, "unknown log density descriptor kind %d", desc->kind);
     if (desc->d <= 0) return set_error(MCMCHIP_EINVAL, "descriptor dimension must be positive");
     mcmchip_target *t = new mcmchip_target();
@@ -175,9 +175,13 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             }
             if (hipMalloc((void **)&t->par, t->host_par.size() * 8) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc failed"); break; }
             if (hipMemcpyAsync(t->par, t->host_par.data(), t->host_par.size() * 8, hipMemcpyHostToDevice, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of descriptor parameters failed"); break; }
-        } else if (!is_logistic(desc->kind) && desc->kind != MCMCHIP_T_BALL) {
+        } else if ((!is_logistic(desc->kind) || desc->kind == MCMCHIP_T_LOGISTIC_MODELS) && desc->kind != MCMCHIP_T_BALL) {
             rc = set_error(MCMCHIP_EINVAL, "descriptor kind %d needs a parameter block", desc->kind);
             break;
+        }
+        if (desc->kind == MCMCHIP_T_LOGISTIC_MODELS) {
+            const long k = (long)t->host_par[0];
+            if (k < 2 || desc->npar != 1 + k * desc->d + k + 1) { rc = set_error(MCMCHIP_EINVAL, "logistic-models descriptor: par must be k, k x d masks, k log pseudo-priors, constant"); break; }
         }
         if (desc->kind == MCMCHIP_T_STUDENT_T && !(t->host_par[0] > 0)) { rc = set_error(MCMCHIP_EINVAL, "Student t descriptor needs df > 0"); break; }
         if (desc->morph_flags) {
@@ -402,6 +406,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     if (a->blen <= 0) return set_error(MCMCHIP_EINVAL, "argument \"blen\" must be positive");
     if (a->nspac <= 0) return set_error(MCMCHIP_EINVAL, "argument \"nspac\" must be positive");
     if (t->kind == MCMCHIP_T_WITCH && t->npar != k) return set_error(MCMCHIP_EINVAL, "witch descriptor needs one bound per component");
+    if (t->kind == MCMCHIP_T_LOGISTIC_MODELS && (int)t->host_par[0] != k) return set_error(MCMCHIP_EINVAL, "logistic-models descriptor has %d components, neighbors has %d", (int)t->host_par[0], k);
     const long nens = a->nens;
     const int nstate = a->parallel ? k * p : p + 1;
     const long niter = (long)a->nbatch * a->blen * a->nspac;
@@ -474,6 +479,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     TemperDev q;
     memset(&q, 0, sizeof q);
     q.kind = t->kind; q.p = p; q.par = t->par; q.npar = t->npar;
+    q.x = t->x; q.y = t->y; q.n = t->n; q.prior_c = t->prior_c;
     q.nens = nens; q.k = k; q.parallel = a->parallel; q.nbatch = a->nbatch; q.blen = a->blen; q.nspac = a->nspac;
     q.neighbors = nbrs.as<int>(); q.initial = init.as<double>();
     q.scale_kind = a->scale_kind; q.scale = scale.as<double>();

@@ -49,6 +49,9 @@ struct TemperDev {
     int kind, p;              // target kind, dimension of theta
     const double *par;
     long npar;
+    const double *x, *y;      // LOGISTIC_MODELS: design matrix n x p and responses
+    long n;
+    double prior_c;
     long nens;
     int k, parallel, nbatch, blen, nspac;
     const int *neighbors;     // k x k

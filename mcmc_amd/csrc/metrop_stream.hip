@@ -231,7 +231,10 @@ __global__ __launch_bounds__(256) void logdens_stream_kernel(TargetView tv, int 
     double v;
     if (temper_kind) {
         const double *s = states + (size_t)c * (tv.d + 1);
-        v = lud_temper(tv.kind, tv.d, tv.par, ncomp, (int)s[0], s + 1);
+        if (tv.kind == MCMCHIP_T_LOGISTIC_MODELS)
+            v = lud_models_group<G>(tv.par, tv.d, tv.x, tv.y, tv.n, tv.prior_c, (int)s[0], s + 1, g);
+        else
+            v = lud_temper(tv.kind, tv.d, tv.par, ncomp, (int)s[0], s + 1);
     } else {
         v = lud_morphed_group<G>(tv, states + (size_t)c * tv.d, ld_w + (size_t)(threadIdx.x / G) * tv.d, g);
     }
@@ -248,7 +251,8 @@ int launch_logdens_stream(const mcmchip_target *t, const double *states, long nc
     tv.morph_center = t->morph_center;
     const size_t wbytes = t->morph_flags ? (size_t)16 * t->d * 8 : 0;
     if (wbytes > 64 * 1024) return set_error(MCMCHIP_EINVAL, "state dimension %d too large for a morphed log density", t->d);
-    int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX);
+    int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX ||
+                       t->kind == MCMCHIP_T_LOGISTIC_MODELS);
     dim3 grid((unsigned)((nchain + 15) / 16)), block(256);
     hipLaunchKernelGGL(logdens_stream_kernel, grid, block, wbytes, s, tv, temper_kind,
                        (long)(t->kind == MCMCHIP_T_WITCH ? t->npar : 0), states, nchain, out);

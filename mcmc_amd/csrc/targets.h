@@ -228,6 +228,30 @@ template <int G> __device__ double lud_morphed_group(const TargetView &t, const 
     return foo + lj;
 }
 
+// model-selection logistic posterior (tests/temp-par.R:39-56, vignettes/bfst.Rnw:472-489), evaluated by the G
+// lanes of one wavefront in lockstep (all lanes pass the same arguments; th may be LDS or global):
+// par = k, k x p masks, k log pseudo-priors, constant.  Every lane returns the same value.
+template <int G>
+__device__ double lud_models_group(const double *par, int p, const double *x, const double *y, long n, double prior_c,
+                                   int i, const double *th, int g)
+{
+    const int k = (int)par[0];
+    const double *mask = par + 1 + (size_t)(i - 1) * p, *lpp = par + 1 + (size_t)k * p;
+    double lp = 0.0, lq = 0.0;
+    for (long r = g; r < n; r += G) {
+        const double *xi = x + (size_t)r * p;
+        double eta = 0.0;
+        for (int j = 0; j < p; j++) eta = add_nofma(eta, mul_nofma(xi[j], mask[j] != 0 ? th[j] : 0.0));
+        if (y[r] == 1.0) lp += (eta < 0) ? eta - log1p(exp(eta)) : -log1p(exp(-eta));
+        else lq += (eta < 0) ? -log1p(exp(eta)) : -eta - log1p(exp(-eta));
+    }
+    lp = group_sum<G>(lp);
+    lq = group_sum<G>(lq);
+    double ss = 0.0;
+    for (int j = 0; j < p; j++) ss += th[j] * th[j];
+    return (lp + lq) - ss * prior_c + lpp[k] + lpp[i - 1];
+}
+
 // temper targets; state = (i, theta[p]) with 1-based component i.  Small p: every lane of the
 // caller evaluates the whole thing (no cooperation), so this is a plain scalar function.
 __device__ inline double lud_temper(int kind, int p, const double *par, int ncomp, int i, const double *th)

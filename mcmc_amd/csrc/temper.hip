@@ -53,6 +53,14 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     double *Ubuf = lds + lay.ubuf, *Zbuf = lds + lay.zbuf;   // Philox draws of the next 64 iterations
     const int pz = (p + 1) & ~1;
 
+    // log density of (component comp, theta): called with wave-uniform arguments only.  The data-carrying
+    // kind spreads its observations over the 64 lanes; the small closed-form kinds are scalar per lane.
+    const bool coop = q.kind == MCMCHIP_T_LOGISTIC_MODELS;
+    auto LUD = [&](int comp, const double *th) -> double {
+        if (coop) return lud_models_group<64>(q.par, p, q.x, q.y, q.n, q.prior_c, comp, th, lane);
+        return lud_temper(q.kind, p, q.par, k, comp, th);
+    };
+
     for (int i = lane; i < nstate; i += 64) S[i] = q.initial[(size_t)e * nstate + i];
     for (int i = lane; i < k; i += 64) {
         int c = 0;
@@ -65,7 +73,20 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     }
     __syncthreads();
     // cached log densities (temper.c:98-119)
-    if (par) {
+    if (par && coop) {
+        for (int i = 0; i < k; i++) {                    // one wave-cooperative evaluation per component
+            for (int j = lane; j < p; j += 64) Y[j] = S[i + k * j];
+            __syncthreads();
+            const double v = LUD(i + 1, Y);
+            if (lane == 0) {
+                L[i] = v;
+                if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+                else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+                else if (isnan(v)) atomicOr(q.flag, FLAG_NAN);
+            }
+            __syncthreads();
+        }
+    } else if (par) {
         for (int i = lane; i < k; i += 64) {
             double th[TEMPER_MAXP];
             for (int j = 0; j < p; j++) th[j] = S[i + k * j];
@@ -78,13 +99,15 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     } else {
         for (int i = lane; i < k; i += 64) L[i] = NAN;
         __syncthreads();
-        if (lane == 0) {
-            int i = (int)S[0];
-            double v = lud_temper(q.kind, p, q.par, k, i, S + 1);
-            L[i - 1] = v;
-            if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
-            else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
-            else if (isnan(v)) atomicOr(q.flag, FLAG_NAN);
+        {
+            const int i = (int)S[0];
+            const double v = coop ? LUD(i, S + 1) : (lane == 0 ? lud_temper(q.kind, p, q.par, k, i, S + 1) : 0.0);
+            if (lane == 0) {
+                L[i - 1] = v;
+                if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+                else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+                else if (isnan(v)) atomicOr(q.flag, FLAG_NAN);
+            }
         }
     }
     __syncthreads();
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                         Y[j] = yj;
                     }
                     __syncthreads();
-                    ly = lud_temper(q.kind, p, q.par, k, ci, Y);
+                    ly = LUD(ci, Y);
                     lh = ly - L[ci - 1];
                     if (q.debug) {   // temper.c:589-609 / 653-665
                         for (int j = lane; j < p; j += 64) {
@@ -179,8 +202,8 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     cj = nb[(ci - 1) * maxnn + pick1(u2, nn[ci - 1]) - 1] + 1;
                     double xi[TEMPER_MAXP], xj[TEMPER_MAXP];
                     for (int j = 0; j < p; j++) { xi[j] = S[(ci - 1) + k * j]; xj[j] = S[(cj - 1) + k * j]; }
-                    sco = lud_temper(q.kind, p, q.par, k, cj, xi);   // (j, x_i) first (temper.c:738-739)
-                    spr = lud_temper(q.kind, p, q.par, k, ci, xj);   // (i, x_j)
+                    sco = LUD(cj, xi);   // (j, x_i) first (temper.c:738-739)
+                    spr = LUD(ci, xj);   // (i, x_j)
                     lh = spr + sco - L[cj - 1] - L[ci - 1];       // temper.c:742-744
                     if (q.debug) {   // coproposal = (i, x_i), proposal = (j, x_j) (temper.c:720-731,757-766)
                         for (int j = lane; j < p; j += 64) {
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                 } else {
                     ci = (int)S[0];
                     cj = nb[(ci - 1) * maxnn + pick1(u1, nn[ci - 1]) - 1] + 1;
-                    ly = lud_temper(q.kind, p, q.par, k, cj, S + 1);
+                    ly = LUD(cj, S + 1);
                     lh = ly - L[ci - 1] + log((double)nn[ci - 1]) - log((double)nn[cj - 1]);   // temper.c:810-812
                     if (q.debug) {   // temper.c:825-835
                         for (int j = lane; j < p; j += 64) { TDBG(q.dbg_proposal, p + 1, j + 1) = S[1 + j]; TDBG(q.dbg_norm, p, j) = NAN; }

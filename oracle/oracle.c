@@ -332,6 +332,25 @@ double orc_lud_temper(const mcmchip_target_desc *t, int i, const double *th)
         double beta = t->par[i];
         return beta * normmix_eval(t->par + 1 + k, d, th);
     }
+    case MCMCHIP_T_LOGISTIC_MODELS: {
+        /* tests/temp-par.R:39-56, vignettes/bfst.Rnw:472-489 */
+        int k = (int)t->par[0];
+        const double *mask = t->par + 1 + (size_t)(i - 1) * d, *lpp = t->par + 1 + (size_t)k * d;
+        double cst = lpp[k];
+        long double lp = 0.0L, lq = 0.0L, ss = 0.0L;
+        for (int64_t r = 0; r < t->n; r++) {
+            const double *xi = t->x + (size_t)r * d;
+            double eta = 0.0;
+            for (int j = 0; j < d; j++) eta += xi[j] * (mask[j] != 0 ? th[j] : 0.0);   /* beta.logl[!inies] <- 0 */
+            if (t->y[r] == 1.0)
+                lp += (eta < 0) ? eta - log1p(exp(eta)) : -log1p(exp(-eta));
+            else
+                lq += (eta < 0) ? -log1p(exp(eta)) : -eta - log1p(exp(-eta));
+        }
+        for (int j = 0; j < d; j++) ss += th[j] * th[j];
+        double logl = (double)lp + (double)lq;
+        return logl - (double)ss * t->prior_c + cst + lpp[i - 1];
+    }
     default:
         return NAN;
     }
@@ -339,7 +358,8 @@ double orc_lud_temper(const mcmchip_target_desc *t, int i, const double *th)
 
 void orc_logdens(const mcmchip_target_desc *t, const double *states, int64_t nchain, double *out)
 {
-    int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX);
+    int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX ||
+                       t->kind == MCMCHIP_T_LOGISTIC_MODELS);
     for (int64_t c = 0; c < nchain; c++) {
         if (temper_kind) {
             const double *s = states + (size_t)c * (t->d + 1);

@@ -18,6 +18,28 @@ def load_logit():
     return X, y
 
 
+def load_foo():
+    """data/foo.txt of the reference (100 rows: x1 x2 x3 y) -> model matrix with intercept, y"""
+    a = np.loadtxt(os.path.join(GOLDEN, "foo.txt"), skiprows=1)
+    y = a[:, 3].copy()
+    X = np.column_stack([np.ones(len(y)), a[:, :3]])
+    return X, y
+
+
+def temp_par_setup():
+    """tests/temp-par.R:8-37: the 8 sub-models of y ~ x1 + x2 + x3, their MLEs (zero for excluded
+    coefficients) and the neighbour graph (models that differ in one predictor)"""
+    X, y = load_foo()
+    models = np.column_stack([np.repeat([0, 1], 4), np.tile(np.repeat([0, 1], 2), 2), np.tile([0, 1], 4)])
+    betas = np.zeros((8, 4))
+    for i, m in enumerate(models):
+        inies = np.concatenate([[True], m.astype(bool)])
+        betas[i, inies] = glm_binomial(X[:, inies], y)
+    neighbors = (models[:, None, :] != models[None, :, :]).sum(axis=2) == 1
+    masks = np.column_stack([np.ones(8), models])
+    return X, y, models, masks, betas, neighbors
+
+
 def glm_binomial(X, y, epsilon=1e-8, maxit=25):
     """R's glm.fit for family = binomial(link = logit), unit weights: IRLS with R's starting
     values, link clamps and convergence rule."""

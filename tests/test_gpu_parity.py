@@ -446,23 +446,59 @@ def _lud_witch(par, p, comp, theta):
     return -(p + 1) * np.log(2) - np.log1p(-(1 - bnd) ** p)
 
 
+_WITCH = _lud_witch
+
+
+def _lud_models(X, y, masks, comp, theta):
+    # tests/temp-par.R:39-56
+    eta = X @ (theta * masks[int(comp) - 1])
+    logp = np.where(eta < 0, eta - np.log1p(np.exp(eta)), -np.log1p(np.exp(-eta)))
+    logq = np.where(eta < 0, -np.log1p(np.exp(eta)), -eta - np.log1p(np.exp(-eta)))
+    return logp[y == 1].sum() + logq[y == 0].sum() - np.sum(theta ** 2) / 2
+
+
 @pytest.mark.parametrize("parallel", [True, False])
-def test_temper_debug_trace_checks(api, oracle_mod, parallel):
+@pytest.mark.parametrize("target", ["witch", "models"])
+def test_temper_debug_trace_checks(api, oracle_mod, parallel, target):
     """The 14 checks of vignettes/debug.Rnw:250-267 as run by tests/temp-par.R:68-218 and
-    tests/temp-ser.R:53-291, on the DEVICE trace, plus bitwise equality with the oracle's trace."""
-    k, p, E = 6, 3, 8
-    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
-    i, j = np.indices((k, k))
-    nb = (np.abs(i - j) == 1) | (np.abs(i - j) == 2)
-    nbatch, blen, nspac, scale = 20, 10, 5, 0.3456789
+    tests/temp-ser.R:53-291, on the DEVICE trace, plus bitwise equality with the oracle's trace.
+    "witch": the witch's hat of temp-par-witch.R; "models": the very configuration of temp-par.R / temp-ser.R
+    (data foo, 8 sub-models, glm starting points, scale 0.56789) for 8 ensembles."""
+    E = 8
+    nbatch, blen, nspac = 20, 10, 5
+    if target == "witch":
+        k, p, scale = 6, 3, 0.3456789
+        par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+        i, j = np.indices((k, k))
+        nb = (np.abs(i - j) == 1) | (np.abs(i - j) == 2)
+        kw = dict(par=par)
+        K = abi.T_WITCH
+        init = np.zeros((E, k, p)) if parallel else np.column_stack([np.ones(E), np.zeros((E, p))])
+        _lud_witch_ = lambda comp, th: _WITCH(par, p, comp, th)
+        ltol = 1e-13
+    else:
+        from rhelpers import temp_par_setup
+        X, y, models, masks, betas, nb = temp_par_setup()
+        k, p, scale = 8, 4, 0.56789
+        kw = dict(x=X, y=y, prior_c=0.5, par=abi.logistic_models_par(masks))
+        K = abi.T_LOGISTIC_MODELS
+        # temp-par.R:63: initial = betas; temp-ser.R: initial = c(nrow(models), betas of the full model)
+        init = np.tile(betas, (E, 1, 1)) if parallel else np.tile(np.concatenate([[8.0], betas[7]]), (E, 1))
+        _lud_witch_ = lambda comp, th: _lud_models(X, y, masks, comp, th)
+        ltol = 1e-10
     niter = nbatch * blen * nspac
     rng = np.random.default_rng(77)
     unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
-    init = np.zeros((E, k, p)) if parallel else np.column_stack([np.ones(E), np.zeros((E, p))])
-    o = api.temper(api.Target(abi.T_WITCH, p, par=par), init, nb, nbatch, blen, nspac, scale, parallel=parallel,
+    o = api.temper(api.Target(K, p, **kw), init, nb, nbatch, blen, nspac, scale, parallel=parallel,
                    unif=unif, norm=norm, debug=True)
-    ref = oracle_mod.temper(oracle_mod.Target(abi.T_WITCH, p, par=par), init, nb, nbatch, blen, nspac, scale,
+    ref = oracle_mod.temper(oracle_mod.Target(K, p, **kw), init, nb, nbatch, blen, nspac, scale,
                             parallel=parallel, unif=unif, norm=norm, debug=True)
+    if target == "models":
+        # data-carrying density: device exp/log1p differ from glibc's in the last bits
+        assert np.array_equal(o["acceptd"], ref["acceptd"]) and np.array_equal(o["state"], ref["state"])
+        assert np.allclose(o["log.hastings"], ref["log.hastings"], rtol=0, atol=1e-11, equal_nan=True)
+        ref = dict(ref)
+        ref["log.hastings"] = o["log.hastings"]
     keys = ["which", "unif.which", "state", "log.hastings", "unif.hastings", "proposal", "acceptd", "norm",
             "unif.choose"] + (["coproposal"] if parallel else [])
     for key in keys:
@@ -494,13 +530,13 @@ def test_temper_debug_trace_checks(api, oracle_mod, parallel):
                 if not which[t]:
                     assert np.array_equal(prop[t, 1:], state[t, pi[t] - 1])
             # 4. hastings ratio
-            f = np.array([_lud_witch(par, p, prop[t, 0], prop[t, 1:]) for t in range(niter)])
-            fc = np.array([_lud_witch(par, p, cop[t, 0], cop[t, 1:]) for t in range(niter)])
-            fs = np.array([_lud_witch(par, p, cop[t, 0], prop[t, 1:]) for t in range(niter)])
-            fcs = np.array([_lud_witch(par, p, prop[t, 0], cop[t, 1:]) for t in range(niter)])
+            f = np.array([_lud_witch_(prop[t, 0], prop[t, 1:]) for t in range(niter)])
+            fc = np.array([_lud_witch_(cop[t, 0], cop[t, 1:]) for t in range(niter)])
+            fs = np.array([_lud_witch_(cop[t, 0], prop[t, 1:]) for t in range(niter)])
+            fcs = np.array([_lud_witch_(prop[t, 0], cop[t, 1:]) for t in range(niter)])
             with np.errstate(invalid="ignore"):
                 want = np.where(which, f - fc, fs + fcs - f - fc)
-            assert np.allclose(want, lh, rtol=1e-13, atol=1e-13)
+            assert np.allclose(want, lh, rtol=ltol, atol=ltol)
             # 7. acceptance carried out
             mine = state.copy()
             for t in range(niter):
@@ -537,11 +573,11 @@ def test_temper_debug_trace_checks(api, oracle_mod, parallel):
         else:
             si, pi = state[:, 0].astype(int), prop[:, 0].astype(int)
             assert np.array_equal(which, pi == si)                                   # temp-ser.R
-            f = np.array([_lud_witch(par, p, state[t, 0], state[t, 1:]) for t in range(niter)])
-            g = np.array([_lud_witch(par, p, prop[t, 0], prop[t, 1:]) for t in range(niter)])
+            f = np.array([_lud_witch_(state[t, 0], state[t, 1:]) for t in range(niter)])
+            g = np.array([_lud_witch_(prop[t, 0], prop[t, 1:]) for t in range(niter)])
             with np.errstate(invalid="ignore"):
                 want = g - f - np.log(nn[pi - 1]) + np.log(nn[si - 1])               # temp-ser-witch.R:95-101
-            assert np.allclose(want, lh, rtol=1e-13, atol=1e-13)
+            assert np.allclose(want, lh, rtol=ltol, atol=ltol)
             mine = np.where(acc[:, None], prop, state)
             assert np.array_equal(after, mine)
             assert np.max(np.abs(prop[which, 1:] - (state[which, 1:] + scale * nrm[which]))) < 1e-15
@@ -657,3 +693,30 @@ def test_morph_descriptor_errors(api):
     tg = api.Target(abi.T_LOGISTIC, 2, x=X, y=y, prior_c=0.125, morph=morph(b=1))
     with pytest.raises(api.McmcHipError, match="MFMA path"):
         api.logdens(tg, np.zeros((4, 2)), path=abi.PATH_MFMA)
+
+
+def test_logistic_models_logdens_and_serial_run(api, oracle_mod):
+    # tests/temp-par.R:58-60 (finite at the sub-model MLEs) through mcmchip_logdens; then a Philox serial-tempering
+    # run replayed by the oracle (the Bayes-factor workload of vignettes/bfst.Rnw: ibatch = time spent per model)
+    from rhelpers import temp_par_setup
+    X, y, models, masks, betas, nb = temp_par_setup()
+    lpp = np.array([0.0, 0.4, 0.1, 0.9, -0.2, 0.3, 0.5, 1.1])
+    kw = dict(x=X, y=y, prior_c=0.125, par=abi.logistic_models_par(masks, lpp, -4 * np.log(2 * np.sqrt(2 * np.pi))))
+    states = np.column_stack([np.arange(1, 9.0), betas])
+    got = api.logdens(api.Target(abi.T_LOGISTIC_MODELS, 4, **kw), states)
+    want = oracle_mod.logdens(oracle_mod.Target(abi.T_LOGISTIC_MODELS, 4, **kw), states)
+    assert np.all(np.isfinite(got)) and np.max(np.abs(got - want)) < 1e-11
+    E = 16
+    init = np.tile(np.concatenate([[8.0], betas[7]]), (E, 1))
+    o = api.temper(api.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init, nb, 30, 10, 3, 0.5, parallel=False, seed=9)
+    ref = oracle_mod.temper(oracle_mod.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init, nb, 30, 10, 3, 0.5,
+                            parallel=False, seed=9)
+    # device Box-Muller (ocml log/sin/cos) and glibc's differ in the last bits, so states agree to rounding, not
+    # bitwise; a flipped decision would show as an O(1) difference
+    same = np.all(np.abs(o["final"] - ref["final"]) <= 1e-9 * (1 + np.abs(ref["final"])), axis=1)
+    assert same.mean() >= 0.9
+    assert np.array_equal(o["ibatch"][same], ref["ibatch"][same])
+    assert np.allclose(o["batch"][same], ref["batch"][same], rtol=1e-9, atol=1e-11)
+    assert np.allclose(o["ibatch"].sum(axis=2), 1.0)
+    with pytest.raises(api.McmcHipError, match="components"):
+        api.temper(api.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init[:, :5], nb[:4, :4], 5, 1, 1, 0.5, parallel=False, seed=1)

@@ -266,3 +266,33 @@ def test_metrop_batching_identities(oracle_mod):
         kept = nxt[2::3]                                                 # state after every nspac-th iteration
         assert np.allclose(o["batch"][0], kept.reshape(20, 5, 5).mean(axis=1)[:, [1, 2]], rtol=1e-15)
         assert np.allclose(o["accept_batch"][0], acc.reshape(20, 15).mean(axis=1))
+
+
+def test_temp_par_setup_matches_transcript(oracle_mod):
+    """tests/temp-par.Rout.save:37-41 prints the glm fit of the full model on data(foo); tests/temp-par.R:58-60
+    requires the density to be finite at every sub-model's MLE.  Pins the foo fixture, the IRLS restatement and
+    the LOGISTIC_MODELS descriptor of the oracle (against a direct numpy evaluation of temp-par.R:39-56)."""
+    from mcmc_amd import abi
+    from rhelpers import temp_par_setup
+    X, y, models, masks, betas, nb = temp_par_setup()
+    assert np.allclose(betas[7], [0.5772, 0.3362, 0.8475, 1.5143], atol=5e-5)
+    assert nb.sum() == 8 * 3 and np.array_equal(nb, nb.T)
+    t = oracle_mod.Target(abi.T_LOGISTIC_MODELS, 4, x=X, y=y, prior_c=0.5, par=abi.logistic_models_par(masks))
+    got = oracle_mod.logdens(t, np.column_stack([np.arange(1, 9.0), betas]))
+    assert np.all(np.isfinite(got))
+    for i in range(8):
+        eta = X @ (betas[i] * masks[i])
+        logp = np.where(eta < 0, eta - np.log1p(np.exp(eta)), -np.log1p(np.exp(-eta)))
+        logq = np.where(eta < 0, -np.log1p(np.exp(eta)), -eta - np.log1p(np.exp(-eta)))
+        want = logp[y == 1].sum() + logq[y == 0].sum() - np.sum(betas[i] ** 2) / 2
+        assert got[i] == pytest.approx(want, rel=1e-13)
+    # bfst.Rnw:472-489 variant: N(0, 2^2) prior with its normalising constant and a log pseudo-prior
+    lpp = np.linspace(-1, 1, 8)
+    cst = -4 * np.log(2 * np.sqrt(2 * np.pi))
+    t2 = oracle_mod.Target(abi.T_LOGISTIC_MODELS, 4, x=X, y=y, prior_c=0.125,
+                           par=abi.logistic_models_par(masks, lpp, cst))
+    got2 = oracle_mod.logdens(t2, np.column_stack([np.arange(1, 9.0), betas]))
+    from scipy.stats import norm
+    for i in range(8):
+        want = got[i] + np.sum(betas[i] ** 2) / 2 + norm.logpdf(betas[i], 0, 2).sum() + lpp[i]
+        assert got2[i] == pytest.approx(want, rel=1e-13)

@@ -78,6 +78,37 @@ def c4():
     return out
 
 
+def c4models():
+    """serial + parallel tempering over the 8 sub-models of tests/temp-par.R (data foo, n = 100, 4 coefficients),
+    1024 ensembles: the reference's Bayes-factor workload (vignettes/bfst.Rnw)"""
+    import oracle
+    from rhelpers import temp_par_setup
+    X, y, models, masks, betas, nb = temp_par_setup()
+    kw = dict(x=X, y=y, prior_c=0.5, par=abi.logistic_models_par(masks))
+    E = 1024
+    out = []
+    for parallel in (True, False):
+        tg = api.Target(abi.T_LOGISTIC_MODELS, 4, **kw)
+        init = np.tile(betas, (E, 1, 1)) if parallel else np.tile(np.concatenate([[8.0], betas[7]]), (E, 1))
+        api.temper(tg, init, nb, 2, 5, 5, 0.56789, parallel=parallel, seed=3)
+        nbatch, blen, nspac = 100, 10, 5
+        t0 = time.perf_counter()
+        o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.56789, parallel=parallel, seed=3)
+        el = time.perf_counter() - t0
+        kn, kms, _ = api.last_kernel_time()
+        niter = nbatch * blen * nspac
+        ot = oracle.Target(abi.T_LOGISTIC_MODELS, 4, **kw)
+        t0 = time.perf_counter()
+        oracle.temper(ot, init[:16], nb, 20, blen, nspac, 0.56789, parallel=parallel, seed=3, nthreads=16)
+        cel = time.perf_counter() - t0
+        out.append({"config": "temper %s, logistic sub-models k=8 p=4 n=100, 1024 ensembles x %d iterations"
+                    % ("parallel" if parallel else "serial", niter),
+                    "ensemble_iter_per_s": E * niter / el, "kernel": kn, "kernel_ms": kms,
+                    "acceptx_mean": float(np.nanmean(o["acceptx"])), "accepti_mean": float(np.nanmean(o["accepti"])),
+                    "cpu_oracle_16thr_ensemble_iter_per_s": 16 * 20 * blen * nspac / cel})
+    return out
+
+
 def c5(n=4_000_000, p=32, blens=(1000,)):
     """initseq + olbm on AR(1) columns resident in HBM (reduced sizes: 4e6 x 32 = 1 GB, 2e6 x 256 = 4 GB)"""
     import torch
@@ -203,6 +234,6 @@ if __name__ == "__main__":
             a = [int(v) for v in w[3:].split(",")]
             r = c5(a[0], a[1], tuple(a[2:]))
         else:
-            r = {"c2": c2, "c4": c4, "c5": c5, "c5p256": lambda: c5(2_000_000, 256)}[w]()
+            r = {"c2": c2, "c4": c4, "c4models": c4models, "c5": c5, "c5p256": lambda: c5(2_000_000, 256)}[w]()
         for line in (r if isinstance(r, list) else [r]):
             print(json.dumps(line))
