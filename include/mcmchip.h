@@ -78,7 +78,11 @@ enum {
      *   sum(logp[y==1]) + sum(logq[y==0]) - prior_c*sum(beta^2) + constant + log_pseudo_prior[i]
      * temp-par.R: prior_c = 1/2, constant = 0, pseudo-priors 0;  bfst.Rnw: sum(dnorm(beta, 0, 2, log=TRUE))
      * = -sum(beta^2)/8 - d*log(2*sqrt(2*pi)), i.e. prior_c = 1/8 and that constant */
-    MCMCHIP_T_LOGISTIC_MODELS = 10
+    MCMCHIP_T_LOGISTIC_MODELS = 10,
+    /* vignettes/morph.Rnw:361-365 (binomial regression with a conjugate prior, the worked example of
+     * morph.metrop): x = M (n x d), y = posterior success counts x_l, par = posterior totals n_l (n doubles)
+     *   MB = M beta;  sum(y * MB) - sum(par * log(1 + exp(MB))) */
+    MCMCHIP_T_BINOMIAL_LOGIT = 11
 };
 
 /* variable transformation of morph.metrop() (R/morph.R:121-181, R/morph.metrop.R): the chain runs on the

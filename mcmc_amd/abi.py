@@ -11,6 +11,7 @@ T_LOGISTIC, T_LOGISTIC_NAIVE, T_MVNORM, T_NORMMIX = 1, 2, 3, 4
 T_SIMPLEX, T_BALL, T_WITCH, T_TEMPERED_NORMMIX = 5, 6, 7, 8
 T_STUDENT_T = 9
 T_LOGISTIC_MODELS = 10
+T_BINOMIAL_LOGIT = 11
 TEMPER_KINDS = (T_WITCH, T_TEMPERED_NORMMIX, T_LOGISTIC_MODELS)
 
 SCALE_CONSTANT, SCALE_DIAGONAL, SCALE_FULL, SCALE_LIST = 1, 2, 3, 8

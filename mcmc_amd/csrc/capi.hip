@@ -122,7 +122,11 @@ int mcmchip_last_kernel_time(double *avg_ms, int64_t *launches, char *name, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-static bool is_logistic(int kind) { return kind == MCMCHIP_T_LOGISTIC || kind == MCMCHIP_T_LOGISTIC_NAIVE || kind == MCMCHIP_T_LOGISTIC_MODELS; }
+static bool is_logistic(int kind)      // kinds that carry a design matrix x (n x d) and a response y (n)
+{
+    return kind == MCMCHIP_T_LOGISTIC || kind == MCMCHIP_T_LOGISTIC_NAIVE || kind == MCMCHIP_T_LOGISTIC_MODELS ||
+           kind == MCMCHIP_T_BINOMIAL_LOGIT;
+}
 static bool is_temper_kind(int kind) { return kind == MCMCHIP_T_WITCH || kind == MCMCHIP_T_TEMPERED_NORMMIX || kind == MCMCHIP_T_LOGISTIC_MODELS; }
 
 int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs, mcmchip_target **out)
@@ -131,7 +135,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
     if (!desc || !out) return set_error(MCMCHIP_EINVAL, "null argument");
     DeviceCtx *dc = cur_dev();
     if (!dc) return MCMCHIP_EHIP;
-    if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_LOGISTIC_MODELS)
+    if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_BINOMIAL_LOGIT)
         return set_error(MCMCHIP_EINVAL, "unknown log density descriptor kind %d", desc->kind);
     if (desc->d <= 0) return set_error(MCMCHIP_EINVAL, "descriptor dimension must be positive");
     mcmchip_target *t = new mcmchip_target();
@@ -175,7 +179,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             }
             if (hipMalloc((void **)&t->par, t->host_par.size() * 8) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc failed"); break; }
             if (hipMemcpyAsync(t->par, t->host_par.data(), t->host_par.size() * 8, hipMemcpyHostToDevice, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of descriptor parameters failed"); break; }
-        } else if ((!is_logistic(desc->kind) || desc->kind == MCMCHIP_T_LOGISTIC_MODELS) && desc->kind != MCMCHIP_T_BALL) {
+        } else if ((!is_logistic(desc->kind) || desc->kind == MCMCHIP_T_LOGISTIC_MODELS || desc->kind == MCMCHIP_T_BINOMIAL_LOGIT) && desc->kind != MCMCHIP_T_BALL) {
             rc = set_error(MCMCHIP_EINVAL, "descriptor kind %d needs a parameter block", desc->kind);
             break;
         }
@@ -183,6 +187,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             const long k = (long)t->host_par[0];
             if (k < 2 || desc->npar != 1 + k * desc->d + k + 1) { rc = set_error(MCMCHIP_EINVAL, "logistic-models descriptor: par must be k, k x d masks, k log pseudo-priors, constant"); break; }
         }
+        if (desc->kind == MCMCHIP_T_BINOMIAL_LOGIT && desc->npar != desc->n) { rc = set_error(MCMCHIP_EINVAL, "binomial descriptor needs one total per row of x"); break; }
         if (desc->kind == MCMCHIP_T_STUDENT_T && !(t->host_par[0] > 0)) { rc = set_error(MCMCHIP_EINVAL, "Student t descriptor needs df > 0"); break; }
         if (desc->morph_flags) {
             // morph() argument rules (R/morph.R:51,75-76)

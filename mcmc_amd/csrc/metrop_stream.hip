@@ -184,7 +184,7 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
 {
     const int d = p.d;
     long work = d;
-    if (p.kind == MCMCHIP_T_LOGISTIC || p.kind == MCMCHIP_T_LOGISTIC_NAIVE) work = p.n;
+    if (p.kind == MCMCHIP_T_LOGISTIC || p.kind == MCMCHIP_T_LOGISTIC_NAIVE || p.kind == MCMCHIP_T_BINOMIAL_LOGIT) work = p.n;
     else if (p.kind == MCMCHIP_T_NORMMIX) work = 8;
     else if (p.morph_flags && d <= 16) work = 1;   // small morphed targets: one lane per chain keeps the norm's summation order
     int G = pick_group(work, p.nchain);

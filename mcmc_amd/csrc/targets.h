@@ -140,6 +140,20 @@ template <int G> __device__ double lud_group(const TargetView &t, const double *
         double fred = 1.0 - s;
         return (fred > 0) ? log(fred) : -INFINITY;
     }
+    case MCMCHIP_T_BINOMIAL_LOGIT: {
+        // vignettes/morph.Rnw:361-365: sum(x * MB) - sum(n * log(1 + exp(MB)))
+        double s1 = 0.0, s2 = 0.0;
+        for (long i = g; i < t.n; i += G) {
+            const double *xi = t.x + (size_t)i * d;
+            double mb = 0.0;
+            for (int j = 0; j < d; j++) mb = add_nofma(mb, mul_nofma(xi[j], v[j]));
+            s1 += t.y[i] * mb;
+            s2 += t.par[i] * log(1 + exp(mb));
+        }
+        s1 = group_sum<G>(s1);
+        s2 = group_sum<G>(s2);
+        return s1 - s2;
+    }
     case MCMCHIP_T_STUDENT_T: {
         // tests/morph.metrop.R:9: sum_j dt(x_j, df, log=TRUE)
         const double df = t.par[0];

@@ -182,6 +182,18 @@ static double lud_base(const mcmchip_target_desc *t, const double *b)
         double fred = 1.0 - (double)s;
         return (fred > 0) ? log(fred) : -INFINITY;
     }
+    case MCMCHIP_T_BINOMIAL_LOGIT: {
+        /* vignettes/morph.Rnw:361-365 */
+        long double s1 = 0.0L, s2 = 0.0L;
+        for (int64_t i = 0; i < t->n; i++) {
+            const double *xi = t->x + (size_t)i * d;
+            double mb = 0.0;
+            for (int j = 0; j < d; j++) mb += xi[j] * b[j];
+            s1 += t->y[i] * mb;
+            s2 += t->par[i] * log(1 + exp(mb));
+        }
+        return (double)s1 - (double)s2;
+    }
     case MCMCHIP_T_STUDENT_T: {
         /* tests/morph.metrop.R:9 dt(x, df, log=TRUE), summed over coordinates.  R's dt() itself (Rmath,
          * not under /root/reference) uses Loader's saddle-point form; this is the textbook density */

@@ -106,7 +106,7 @@ def test_metrop_trace_scale_and_outfun(api, oracle_mod, logit, scale_kind, outfu
     assert np.allclose(o["accept"], o["accept.batch"].mean(axis=1))
 
 
-@pytest.mark.parametrize("kind", ["simplex", "ball", "mvnorm", "normmix", "naive"])
+@pytest.mark.parametrize("kind", ["simplex", "ball", "mvnorm", "normmix", "naive", "binomial", "student"])
 def test_metrop_other_targets(api, oracle_mod, logit, kind):
     rng = np.random.default_rng(5)
     d = 5
@@ -123,6 +123,15 @@ def test_metrop_other_targets(api, oracle_mod, logit, kind):
     elif kind == "normmix":
         par = abi.normmix_par([0.5, 0.3, 0.2], rng.standard_normal((3, d)) * 2, [1.0, 0.5, 2.0])
         K, kw, scale = abi.T_NORMMIX, dict(par=par), 1.0
+        init = rng.standard_normal((32, d))
+    elif kind == "binomial":
+        # vignettes/morph.Rnw:361-400: 12 gender x department cells, counts + nu = 5 prior students at xi = 0.3
+        M = np.column_stack([np.ones(12), rng.integers(0, 2, 12), rng.integers(0, 2, (12, 3))]).astype(float)
+        tot = rng.integers(20, 900, 12).astype(float)
+        K, kw, scale = abi.T_BINOMIAL_LOGIT, dict(x=M, y=np.floor(tot * rng.random(12)) + 1.5, par=tot + 5.0), 0.1
+        init = 0.1 * rng.standard_normal((32, d))
+    elif kind == "student":
+        K, kw, scale = abi.T_STUDENT_T, dict(par=[3.0]), 1.5                    # tests/morph.metrop.R:9
         init = rng.standard_normal((32, d))
     else:
         X, y, mle = logit
