@@ -383,10 +383,12 @@ def initseq(x):
     return res[0] if single else res
 
 
-def olbm(x, batch_length, demean=True):
+def olbm(x, batch_length, demean=True, mean=None):
     """olbm(x, batch.length, demean = TRUE): R/olbm.R:2-24.  x is n x p (a vector is n x 1).
     Like the reference, demean = FALSE zeroes `mean` but leaves no.calc.mean FALSE, so the
-    native routine recomputes the means (R/olbm.R:8-14 with olbm.c:37): both settings demean."""
+    native routine recomputes the means (R/olbm.R:8-14 with olbm.c:37): both settings demean.
+    mean (not an argument of the R front end): the native routine's no.calc.mean = TRUE contract with means
+    supplied by the caller (olbm.c:37-43), used by the time-sharded driver mcmc_amd.dist.olbm_sharded."""
     x = np.asarray(x, dtype=np.float64)
     if x.ndim == 1:
         x = x[:, None]
@@ -395,7 +397,12 @@ def olbm(x, batch_length, demean=True):
     if batch_length > n:
         raise ValueError("batch.length must be <= nrow(x)")
     xc = np.ascontiguousarray(x.T)                           # column-major n x p
-    if demean:
+    if mean is not None:
+        mean = np.asarray(mean, dtype=np.float64).copy()
+        if mean.shape != (p,):
+            raise ValueError("mean must have one entry per column")
+        no_calc_mean = True
+    elif demean:
         mean = x.mean(axis=0)
         no_calc_mean = True
     else:

@@ -58,3 +58,111 @@ def metrop_sharded(run_local, initial, group=None, device=None):
     out["accept.all"] = all_gather_rows(np.atleast_1d(out["accept"]), group, device)
     out["accept.batch.all"] = all_gather_rows(out["accept.batch"], group, device)
     return out
+
+
+def all_reduce_sum(local, group=None, device=None):
+    """sum a small numpy array over the ranks (RCCL all-reduce / gloo)"""
+    import torch
+    import torch.distributed as dist
+
+    a = np.ascontiguousarray(local, dtype=np.float64)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return a
+    t = torch.from_numpy(a.copy())
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+def temper_sharded(run_local, initial, group=None, device=None):
+    """ensembles are independent (the k components of one ensemble stay on one GPU): rank r runs
+    run_local(initial_block, ens_offset) -> result dict of mcmc_amd.temper; batch means and the acceptance
+    tables of ALL ensembles are gathered under "<name>.all" (SURVEY.md 8(e), row temper)."""
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    initial = np.asarray(initial)
+    lo, hi = shard_range(initial.shape[0], rank, ws)
+    out = run_local(initial[lo:hi], lo)
+    out["shard"] = (lo, hi)
+    for key in ("batch", "acceptx", "accepti", "ibatch"):
+        if key in out and out[key] is not None:
+            out[key + ".all"] = all_gather_rows(out[key], group, device)
+    return out
+
+
+def initseq_sharded(run_local, ncol, group=None, device=None):
+    """initseq by functional (column): rank r computes run_local(col_lo, col_hi) -> list of mcmc_amd.initseq results
+    for its columns; the scalar outputs of all columns are gathered as arrays, the Gamma sequences as NaN-padded
+    matrices with their lengths (SURVEY.md 8(e), row initseq: no communication but this gather)."""
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = shard_range(ncol, rank, ws)
+    res = run_local(lo, hi) if hi > lo else []
+    out = {"shard": (lo, hi), "local": res}
+    for key in ("gamma0", "var.pos", "var.dec", "var.con"):
+        out[key] = all_gather_rows(np.array([r[key] for r in res], dtype=np.float64).reshape(-1), group, device)
+    lens = all_gather_rows(np.array([len(r["Gamma.pos"]) for r in res], dtype=np.float64).reshape(-1), group, device)
+    out["length"] = lens.astype(np.int64)
+    width = int(all_reduce_max(max([len(r["Gamma.pos"]) for r in res], default=0), group, device))
+    for key in ("Gamma.pos", "Gamma.dec", "Gamma.con"):
+        pad = np.full((len(res), width), np.nan)
+        for i, r in enumerate(res):
+            pad[i, : len(r[key])] = r[key]
+        out[key] = all_gather_rows(pad, group, device)
+    return out
+
+
+def all_reduce_max(value, group=None, device=None):
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def olbm_time_shard(n, batch_length, rank, world_size):
+    """rows [row_lo, row_hi) of the n x p series that rank `rank` needs for its share of the n - len + 1 windows
+    (its windows plus a halo of len - 1 rows), and how many of them it owns for the column means"""
+    nwin = int(n) - int(batch_length) + 1
+    w_lo, w_hi = shard_range(nwin, rank, world_size)
+    row_hi = w_hi + int(batch_length) - 1 if w_hi > w_lo else w_lo
+    own = (int(n) - w_lo) if rank == world_size - 1 else (w_hi - w_lo)
+    return w_lo, row_hi, own
+
+
+def olbm_sharded(olbm_local, x_local, n, batch_length, group=None, device=None):
+    """olbm by time (SURVEY.md 8(e), row olbm): every rank holds rows olbm_time_shard(...) of the series.
+    Two exchange steps, both tiny: an all-reduce of the column sums (p doubles) for the global means, and an
+    all-reduce of the un-normalised p x p sum of outer products.  olbm_local(x, len, mean) must return the
+    `nocalc` result of mcmc_amd.olbm's entry point for that block (var normalised by the block's own
+    nbatch * n * len, olbm.c:28,74), which is undone here before the reduction."""
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    x_local = np.asarray(x_local, dtype=np.float64)
+    lo, hi, own = olbm_time_shard(n, batch_length, rank, ws)
+    if x_local.shape[0] != hi - lo:
+        raise ValueError("rank %d must hold rows [%d, %d) of the series" % (rank, lo, hi))
+    p = x_local.shape[1]
+    mean = all_reduce_sum(x_local[:own].sum(axis=0), group, device) / float(n)
+    n_loc = hi - lo
+    nwin_loc = n_loc - int(batch_length) + 1
+    if nwin_loc > 0:
+        var_loc = np.asarray(olbm_local(x_local, int(batch_length), mean))
+        part = var_loc * (float(nwin_loc) * float(n_loc) * float(batch_length))
+    else:
+        part = np.zeros((p, p))
+    total = all_reduce_sum(part, group, device)
+    nwin = int(n) - int(batch_length) + 1
+    return total / (float(nwin) * float(n) * float(batch_length)), mean

@@ -729,3 +729,25 @@ def test_logistic_models_logdens_and_serial_run(api, oracle_mod):
     assert np.allclose(o["ibatch"].sum(axis=2), 1.0)
     with pytest.raises(api.McmcHipError, match="components"):
         api.temper(api.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init[:, :5], nb[:4, :4], 5, 1, 1, 0.5, parallel=False, seed=1)
+
+
+def test_olbm_time_sharding_arithmetic_on_device(api, oracle_mod):
+    # mcmc_amd/dist.py::olbm_sharded with the device entry point, ranks emulated in turn (no process group):
+    # blocks with a len-1 halo, global means given (nocalc contract), un-normalised partial sums added
+    from mcmc_amd import dist as mdist
+    rng = np.random.default_rng(21)
+    n, p, blen, ws = 30011, 20, 97, 3
+    x = np.cumsum(rng.standard_normal((n, p)) * 0.05, axis=0) + rng.standard_normal((n, p)) + 1.0
+    mean = x.mean(axis=0)
+    total = np.zeros((p, p))
+    rows = 0
+    for r in range(ws):
+        lo, hi, own = mdist.olbm_time_shard(n, blen, r, ws)
+        rows += own
+        blk = x[lo:hi]
+        nwin = blk.shape[0] - blen + 1
+        total += api.olbm(blk, blen, mean=mean) * (float(nwin) * blk.shape[0] * blen)
+    assert rows == n
+    got = total / (float(n - blen + 1) * n * blen)
+    ref, _ = oracle_mod.olbm(x, blen)
+    assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))

@@ -151,13 +151,49 @@ assert out["shard"] == ((0, 4) if dist.get_rank() == 0 else (4, 7))
 assert np.array_equal(out["batch.all"], whole["batch"])
 assert np.array_equal(out["accept.all"], whole["accept"])
 assert np.array_equal(out["accept.batch.all"], whole["accept_batch"])
+
+# temper: ensembles sharded, tables gathered
+par = 1 - 0.5 ** (1 / 2) * 0.25 ** (np.arange(4) / 2)
+wt = oracle.Target(abi.T_WITCH, 2, par=par)
+nb = np.abs(np.subtract.outer(np.arange(4), np.arange(4))) == 1
+tinit = np.zeros((5, 4, 2))                   # ragged: 3 + 2 ensembles
+def run_t(block, lo):
+    return oracle.temper(wt, block, nb, 6, 4, 2, 0.3, parallel=True, seed=8, ens_offset=lo)
+tout = mdist.temper_sharded(run_t, tinit)
+twhole = oracle.temper(wt, tinit, nb, 6, 4, 2, 0.3, parallel=True, seed=8)
+for key in ("batch", "acceptx", "accepti"):
+    assert np.array_equal(tout[key + ".all"], twhole[key], equal_nan=True), key
+
+# initseq: functionals (columns) sharded, ragged Gamma sequences gathered
+rng = np.random.default_rng(3)
+cols = []
+for rho in (0.2, 0.9, 0.6):
+    e = rng.standard_normal(3000)
+    x = np.empty(3000); x[0] = e[0]
+    for t in range(1, 3000): x[t] = rho * x[t - 1] + e[t]
+    cols.append(x - x.mean())
+iout = mdist.initseq_sharded(lambda lo, hi: [oracle.initseq(cols[c]) for c in range(lo, hi)], 3)
+for c in range(3):
+    ref = oracle.initseq(cols[c])
+    m = len(ref["Gamma.pos"])
+    assert iout["length"][c] == m and iout["var.con"][c] == ref["var.con"] and iout["gamma0"][c] == ref["gamma0"]
+    assert np.array_equal(iout["Gamma.con"][c, :m], ref["Gamma.con"]) and np.all(np.isnan(iout["Gamma.con"][c, m:]))
+
+# olbm: time sharded with a halo, two small all-reduces
+xs = np.column_stack(cols) + 2.0
+n, blen = xs.shape[0], 50
+lo, hi, own = mdist.olbm_time_shard(n, blen, dist.get_rank(), 2)
+var, mean = mdist.olbm_sharded(lambda xb, l, m: oracle.olbm(xb, l, mean=m)[0], xs[lo:hi], n, blen)
+vref, mref = oracle.olbm(xs, blen)
+assert np.allclose(mean, mref, rtol=1e-14) and np.max(np.abs(var - vref)) <= 1e-12 * np.max(np.abs(vref))
 dist.destroy_process_group()
 print("ok")
 '''
 
 
 def test_sharded_metrop_world_size_2_gloo(oracle_mod):
-    # N>1 path: shard chains over ranks, Philox keyed by global chain id, one all-gather at the end.
+    # N>1 path: shard chains over ranks, Philox keyed by global chain id, one all-gather at the end; likewise
+    # temper (ensembles), initseq (columns) and olbm (time + halo, two small all-reduces).
     # (the oracle stands in for the device sampler here: what is under test is the sharding)
     import socket
     s = socket.socket()
