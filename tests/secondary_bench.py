@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Secondary measurements (not the headline bench): BASELINE.json configs 2, 4 and a reduced 5.
-Prints one JSON line per config.  usage: python tools/bench_other.py [c2] [c4] [c5]"""
+"""Secondary measurements (not the headline bench): BASELINE.json configs 2, 4 and 5, each beside the CPU oracle.
+It lives under tests/ because it times the oracle next to the device path (only tests/, smoke() and bench.py's
+cpu_baseline leg may use oracle/); pytest does not collect it.
+Prints one JSON line per config.  usage: python tests/secondary_bench.py [c2] [c4] [c4models] [c5] [c5dev=n,p,len]"""
 import ctypes as C
 import json
 import os
@@ -11,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # rhelpers
 
 from mcmc_amd import abi, api  # noqa: E402
 
