@@ -111,12 +111,12 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
                                                                const SoftplusTables *__restrict__ tab)
 {
     constexpr int CHUNK = TC * KS * 64;               // doubles per LDS buffer (16 KB)
-    __shared__ __attribute__((aligned(16))) double smem[2 * CHUNK + 2 * SP_N];
+    __shared__ __attribute__((aligned(16))) double smem[2 * CHUNK + SP_TAB_DOUBLES];
     double *sX = smem;
     double *sTab = smem + 2 * CHUNK;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 2 * SP_N; i += NW * 64) sTab[i] = tab->e[i];
+    for (int i = threadIdx.x; i < SP_TAB_DOUBLES; i += NW * 64) sTab[i] = tab->e[i];
 
     // loop-invariant B fragments: Theta[k = 4ks + (lane>>4)][chain = chain0 + 16c + (lane&15)]
     const long chain0 = ((long)blockIdx.x * NW + wave) * 16 * NC;
@@ -147,48 +147,77 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         }
     };
 
-    double sum[NC], sabs[NC];     // sum of L(|eta|), sum of |eta|
+    double sum[NC];               // sum of M(eta) = |eta|/2 + L(|eta|)
 #pragma unroll
-    for (int c = 0; c < NC; c++) sum[c] = sabs[c] = 0.0;
+    for (int c = 0; c < NC; c++) sum[c] = 0.0;
 
     if (nchunks > 0) stage(0, 0);
     __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the table
 
+    // One tile = KS*NC MFMAs into a fresh accumulator set.  The softplus epilogue of a tile (softplus.h: per
+    // value 10 VALU instructions + the add below and 4 ds_read_b128) is software-pipelined one tile behind: it is
+    // issued in the same basic block as the NEXT tile's MFMAs and spread between them with sched_group_barrier,
+    // so the latency of its table reads is covered by MFMAs in flight (measured: 156.8 -> 152.3 ms per launch;
+    // its VALU instructions themselves cannot overlap the fp64 MFMA, see softplus.h).
+    auto mfma_tile = [&](const double *xs, int tt, double4_t *acc) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const double a = xs[(tt * KS + ks) * 64];
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][c], acc[c], 0, 0, 0);
+        }
+    };
+    // min(eta,0) - L(|eta|) = eta/2 - M(eta): sum(eta) is linear in Theta (colsum . theta, added by the update
+    // kernel), so only M(eta) = |eta|/2 + L(|eta|) is accumulated here
+    auto epilogue = [&](const double4_t *acc) {
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sum[c] += softplus_half_abs(acc[c][r], sTab);
+    };
+    auto interleave = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // the first X fragments
+#pragma unroll
+        for (int i = 0; i < KS * NC / 2; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // four VALU of the trailing epilogue
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // LDS reads: table pairs, X fragments
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+
+    double4_t acc2[2][NC];        // ping-pong accumulators: tile tt uses acc2[tt & 1]
+    static_assert(TC % 2 == 0, "the last tile of a chunk must leave its accumulators in acc2[1]");
     for (long ch = 0; ch < nchunks; ch++) {
         const int buf = (int)(ch & 1);
         if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
         const double *xs = sX + buf * CHUNK + lane;
+        if (ch == 0) {
+            mfma_tile(xs, 0, acc2[0]);
+        } else {
+            mfma_tile(xs, 0, acc2[0]);
+            epilogue(acc2[1]);                 // the last tile of the previous chunk
+            interleave();
+        }
 #pragma unroll
-        for (int tt = 0; tt < TC; tt++) {
-            double4_t acc[NC];
-#pragma unroll
-            for (int c = 0; c < NC; c++) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                const double a = xs[(tt * KS + ks) * 64];
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][c], acc[c], 0, 0, 0);
-            }
-            // softplus epilogue straight from the accumulators.  min(eta,0) - L(|eta|) is split as
-            // (eta - |eta|)/2 - L: sum(eta) is linear in Theta (colsum . theta, added by the update
-            // kernel), so only |eta| and L are accumulated here.
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double eta = acc[c][r];
-                    sabs[c] += fabs(eta);
-                    sum[c] += softplus_neg(sp_clamp_abs(eta), sTab);
-                }
+        for (int tt = 1; tt < TC; tt++) {
+            mfma_tile(xs, tt, acc2[tt & 1]);
+            epilogue(acc2[(tt + 1) & 1]);
+            interleave();
         }
         __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
     }
+    if (nchunks > 0) epilogue(acc2[1]);
 
     // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        double v = fma(0.5, sabs[c], sum[c]);          // partial = sum(|eta|)/2 + sum(L); the update kernel negates
+        double v = sum[c];                             // partial = sum(|eta|)/2 + sum(L); the update kernel negates
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (lane < 16) partial[(size_t)blockIdx.y * ldc + chain0 + 16 * c + lane] = v;

@@ -1,20 +1,32 @@
-// softplus.h -- branch-free fp64 L(a) = log1p(exp(-a)), a >= 0, for the logistic log density.
+// softplus.h -- branch-free fp64 M(eta) = |eta|/2 + log1p(exp(-|eta|)) for the logistic log density.
 //
 // The reference evaluates, per observation (vignettes/demo.Rnw:61-62),
 //     logp = eta<0 ? eta - log1p(exp(eta)) : -log1p(exp(-eta))
 //     logq = eta<0 ? -log1p(exp(eta))      : -eta - log1p(exp(-eta))
-// i.e. with s = +1 for y==1 and -1 for y==0:  min(s*eta, 0) - L(|eta|).
+// i.e. with s = +1 for y==1 and -1 for y==0:  min(s*eta, 0) - L(|eta|) = s*eta/2 - M(eta),
+// L(a) = log1p(exp(-a)).  The s*eta/2 part is linear in theta (a column-sum dot product, added by the update
+// kernel), so the per-observation work is M alone.
 //
 // On gfx950 the fp64 MFMA and the fp64 VALU share one pipe (profiles/r1_mfma64_probe.txt): every
 // fp64 VALU op of this epilogue is paid in MFMA time, so the op count is what matters.  Library
-// exp()/log1p() cost ~150 fp64 ops.  Here, with a = a_j + r on a grid a_j = j/128 (|r| <= 1/256):
-//     L(a) = L(a_j) + log1p( sigma_j * expm1(-r) ),   sigma_j = e^{-a_j} / (1 + e^{-a_j})
-// one 16-byte table entry {L_j, -sigma_j} (73.7 KB in LDS, one ds_read_b128), a degree-5 expm1
-// and a degree-5 log1p: 15 fp64 ops + 1 integer op.  Both series act on small arguments
-// (|v| <= 0.002), so L keeps its relative accuracy when it is tiny (a large).
-// For a > 36 the value is held at L(36) = 2.3e-16 (absolute error <= 2.3e-16).
+// exp()/log1p() cost ~150 fp64 ops; the previous version of this file (table of {L_j, sigma_j} + an expm1 and a
+// log1p series, clamp and a separate sum of |eta|) cost 17.  Here M is expanded directly around the nearest
+// point of a grid a_j = j/56.5, j = 0..2034 (|r| <= 1/113):
+//     M(a_j + r) = c0 + r (c1 + r (c2 + r (c3 + r (c4 + r (c5 + r c6))))),   c_k = M^(k)(a_j) / k!
+// (remainder <= |L^(7)|/7! * r^7 < 1e-18).  Eight doubles per entry {a_j, c0..c6} = 130 KB of LDS, as two arrays
+// of 32-byte records ({a_j,c0,c1,c2} and {c3,c4,c5,c6}: four ds_read_b128 off one address register).
+// Measured on the box (exp builds of the MFMA kernel): v_mfma_f64_16x16x4 occupies the SIMD's VALU for its 64
+// cycles, so EVERY VALU instruction of the epilogue -- integer ones too -- adds its issue time to the kernel,
+// while the table reads themselves cost almost nothing.  The epilogue is therefore written for instruction
+// count: 1 v_min_f64 (clamp for the index), 1 fma (index), 1 shift (address), 1 subtract (r), 6 fma, and the
+// caller's running sum = **11 VALU instructions** per value (the {L_j, sigma_j} + expm1/log1p-series version
+// before it: 20).
+// Beyond the table (|eta| > 36) the index stays in the last cell (the clamp) while r keeps growing, and the last
+// record holds the line c0 + r/2 (L(36) = 2.3e-16 is constant to 1 ulp of M there; its higher coefficients are
+// 1e-300 rather than 0 so that |eta| = Inf gives +Inf, not NaN; |eta| up to 1e40 is exact to rounding).
+// NaN propagates.
 //
-// Accuracy (tools/check_softplus.py against long-double log1pl(expl(-a))): <= 2 ulp (mean 0.4) on [0, 36].
+// Accuracy (tools/check_softplus.py against long double): <= 2 ulp of M (mean 0.3) for |eta| up to 1e30.
 // The same source compiles for the host (g++) so the arithmetic can be checked without a GPU.
 #pragma once
 #include <math.h>
@@ -28,61 +40,80 @@
 #endif
 
 #define SP_AMAX 36
-#define SP_INV_H 128
-#define SP_N (SP_AMAX * SP_INV_H + 1)
+#define SP_SCALE 56.5                        // grid points per unit (exact in binary)
+#define SP_N 2035                            // SP_AMAX * SP_SCALE + 1
+#define SP_DEG 6
+#define SP_ACLAMP 36.0078125                 // < 36 + 0.5/SP_SCALE: the index never leaves the table
 
 struct SoftplusTables {
-    double e[2 * SP_N];   // {L_j, -sigma_j}
+    double e[4 * 2 * SP_N];   // SP_N records {a_j, c0, c1, c2}, then SP_N records {c3, c4, c5, c6}
 };
+#define SP_TAB_DOUBLES (4 * 2 * SP_N)
 
 SP_HD double sp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-SP_HD int32_t sp_lo(double x) { int64_t b; memcpy(&b, &x, 8); return (int32_t)b; }
 
-// min(|eta|, SP_AMAX).  On the device one v_min_f64 with the |.| source modifier: written as
-// inline asm because the compiler's fmin() first canonicalises its operand (an extra
-// v_max_f64 x,x per call) when it cannot prove the MFMA result is not a signalling NaN.
-SP_HD double sp_clamp_abs(double eta)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    double a;
-    asm("v_min_f64 %0, |%1|, %2" : "=v"(a) : "v"(eta), "s"((double)SP_AMAX));
-    return a;
-#else
-    const double a = fabs(eta);
-    return a < (double)SP_AMAX ? a : (double)SP_AMAX;
-#endif
-}
-
-// a must already be clamped to [0, SP_AMAX] (sp_clamp_abs); tab may live in LDS or host memory
-SP_HD double softplus_neg(double a, const double *tab)
+// tab may live in LDS or host memory.  Layout: SP_N records {a_j, c0, c1, c2}, then SP_N records {c3, c4, c5, c6}.
+SP_HD double softplus_half_abs(double eta, const double *tab)
 {
     const double SHIFT = 6755399441055744.0;   // 1.5 * 2^52: low mantissa bits of (x + SHIFT) = rint(x)
-    const double jd = sp_fma(a, (double)SP_INV_H, SHIFT);
-    const int32_t j = sp_lo(jd);
-    const double jf = jd - SHIFT;
-    const double r = sp_fma(jf, -1.0 / SP_INV_H, a);          // exact: a - j/128
-    const double Lj = tab[2 * j], nsig = tab[2 * j + 1];
-    // expm1(-r) = -r * (1 - r/2 + r^2/6 - r^3/24 + r^4/120)
-    double q = sp_fma(r, 1.0 / 120, -1.0 / 24);
-    q = sp_fma(r, q, 1.0 / 6);
-    q = sp_fma(r, q, -0.5);
-    q = sp_fma(r, q, 1.0);
-    const double v = (nsig * r) * q;                           // sigma_j * expm1(-r)
-    // log1p(v) = v * (1 - v/2 + v^2/3 - v^3/4 + v^4/5)
-    double P = sp_fma(v, 0.2, -0.25);
-    P = sp_fma(v, P, 1.0 / 3);
-    P = sp_fma(v, P, -0.5);
-    P = sp_fma(v, P, 1.0);
-    return sp_fma(v, P, Lj);
+    // index from |eta| clamped just inside the last cell (one v_min_f64 with the |.| modifier; NaN -> last cell),
+    // remainder from the unclamped |eta|: past the table the last record is the line c0 + r/2
+#if defined(__HIP_DEVICE_COMPILE__)
+    double ac;
+    asm("v_min_f64 %0, |%1|, %2" : "=v"(ac) : "v"(eta), "s"((double)SP_ACLAMP));
+#else
+    const double ab = __builtin_fabs(eta);
+    const double ac = ab < (double)SP_ACLAMP ? ab : (double)SP_ACLAMP;    // NaN: comparison false -> clamp
+#endif
+    const double jd = sp_fma(ac, SP_SCALE, SHIFT);
+    int64_t bits;
+    memcpy(&bits, &jd, 8);
+    const uint32_t j = (uint32_t)bits;           // 0 .. SP_N-1 by construction of the clamp
+    const double *t0 = tab + 4 * j, *t1 = t0 + 4 * SP_N;
+    const double r = __builtin_fabs(eta) - t0[0];
+    double q = sp_fma(r, t1[3], t1[2]);
+    q = sp_fma(r, q, t1[1]);
+    q = sp_fma(r, q, t1[0]);
+    q = sp_fma(r, q, t0[3]);
+    q = sp_fma(r, q, t0[2]);
+    return sp_fma(r, q, t0[1]);
 }
 
-// host-side table construction in long double
+// host-side table construction in long double.  L^(k)(a) is a polynomial p_k in s = e^-a / (1 + e^-a):
+// p_1 = -s and p_{k+1}(s) = p_k'(s) * (-s (1 - s))  (ds/da = -s(1-s)).
 static inline void softplus_tables_init(SoftplusTables *t)
 {
+    long double poly[SP_DEG + 1][SP_DEG + 2];     // poly[k][m]: coefficient of s^m in p_k
+    memset(poly, 0, sizeof poly);
+    poly[1][1] = -1.0L;
+    for (int k = 1; k < SP_DEG; k++)
+        for (int m = 1; m <= k; m++) {
+            // d/ds (c s^m) * (-s + s^2) = c m (-s^m + s^(m+1))
+            poly[k + 1][m] += -poly[k][m] * m;
+            poly[k + 1][m + 1] += poly[k][m] * m;
+        }
+    long double fact = 1.0L;
+    long double kfact[SP_DEG + 1];
+    kfact[0] = 1.0L;
+    for (int k = 1; k <= SP_DEG; k++) { fact *= k; kfact[k] = fact; }
     for (int j = 0; j < SP_N; j++) {
-        const long double aj = (long double)j / SP_INV_H;
-        const long double ex = expl(-aj);
-        t->e[2 * j] = (double)log1pl(ex);
-        t->e[2 * j + 1] = (double)(-ex / (1.0L + ex));
+        const double aj = (double)((long double)j / (long double)SP_SCALE);
+        const long double ex = expl(-(long double)aj);
+        const long double s = ex / (1.0L + ex);
+        double c[SP_DEG + 1];
+        c[0] = (double)((long double)aj / 2 + log1pl(ex));
+        for (int k = 1; k <= SP_DEG; k++) {
+            long double v = 0.0L;
+            for (int m = k; m >= 1; m--) v = v * s + poly[k][m];     // Horner in s, p_k has no constant term
+            v *= s;
+            c[k] = (double)(v / kfact[k] + (k == 1 ? 0.5L : 0.0L));
+        }
+        if (j == SP_N - 1) {                       // the line beyond the table
+            c[1] = 0.5;
+            for (int k = 2; k <= SP_DEG; k++) c[k] = 1e-300;
+        }
+        double *r0 = t->e + 4 * j, *r1 = t->e + 4 * SP_N + 4 * j;
+        r0[0] = aj;   r0[1] = c[0]; r0[2] = c[1]; r0[3] = c[2];
+        r1[0] = c[3]; r1[1] = c[4]; r1[2] = c[5]; r1[3] = c[6];
     }
 }

@@ -122,15 +122,16 @@ def test_oracle_philox_sharding_and_restart(oracle_mod):
 
 
 def test_softplus_arithmetic_accuracy():
-    # the MFMA path's table-driven log1p(exp(-a)) (mcmc_amd/csrc/softplus.h), compiled for the host
+    # the MFMA path's table-driven M(eta) = |eta|/2 + log1p(exp(-|eta|)) (mcmc_amd/csrc/softplus.h), host build
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_softplus
     rng = np.random.default_rng(0)
-    a = np.concatenate([rng.uniform(0, 36, 300000), np.arange(0, 4609) / 128.0, [0.0, 1e-300, 36.0, 40.0, 745.0, 1e4]])
+    a = np.concatenate([rng.uniform(-36, 36, 300000), np.arange(0, 2035) / 56.5, (np.arange(0, 2035) + 0.5) / 56.5,
+                        [0.0, -0.0, 1e-300, 36.0, 36.01, 40.0, -745.0, 1e4, 1e9, 1e30]])
     out, ref = check_softplus.run(a)
-    ok = a <= 36
-    assert np.max(np.abs(out[ok] - ref[ok]) / ref[ok]) < 2.5 * 2.0 ** -53
-    assert np.all(np.abs(out[~ok] - ref[~ok]) < 2.4e-16)      # held at L(36) beyond the table
+    assert np.max(np.abs(out - ref) / ref) < 2.5 * 2.0 ** -53
+    edge, _ = check_softplus.run(np.array([np.inf, -np.inf, np.nan]))
+    assert edge[0] == np.inf and edge[1] == np.inf and np.isnan(edge[2])
 
 
 _WORKER = r'''

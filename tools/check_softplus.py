@@ -32,10 +32,12 @@ def run(a):
 
 if __name__ == "__main__":
     rng = np.random.default_rng(1)
-    a = np.concatenate([rng.uniform(0, 36, 3_000_000), rng.uniform(0, 1, 500000),
-                        [0.0, 1e-300, 1e-17, 35.999, 36.0], np.arange(0, 4609) / 128.0,
-                        np.arange(0, 4608) / 128.0 + 1 / 256.0])
+    a = np.concatenate([rng.uniform(-36, 36, 3_000_000), rng.uniform(0, 1, 500000), rng.uniform(36, 1e6, 100000),
+                        [0.0, -0.0, 1e-300, 1e-17, 35.999, 36.0, 36.01, 1e9, 1e12, 1e30],
+                        np.arange(0, 2035) / 56.5, (np.arange(0, 2035) + 0.5) / 56.5])
     out, ref = run(a)
     rel = np.abs(out - ref) / np.abs(ref) / 2.0 ** -53
     print("max err %.3f ulp at a=%r; mean %.3f ulp" % (rel.max(), a[rel.argmax()], rel.mean()))
-    sys.exit(0 if rel.max() < 2.5 else 1)
+    o2, _ = run(np.array([np.inf, -np.inf, np.nan]))
+    print("inf, -inf, nan ->", o2)
+    sys.exit(0 if rel.max() < 2.5 and o2[0] == np.inf and o2[1] == np.inf and np.isnan(o2[2]) else 1)
