@@ -187,6 +187,16 @@ typedef struct mcmchip_metrop_out {
  * nspac, scale, func2, debug, parallel, rho1, rho2) (mcmc.h:10-12,
  * temper.c:17-913).  `nens` independent ensembles advance in lockstep.   */
 /* ------------------------------------------------------------------ */
+/* output functionals of temper (func2 of temper.c:17; NULL = identity, temper.c:851-867) */
+enum {
+    MCMCHIP_TOUT_IDENTITY = 0,   /* parallel: the k x p state; serial: x (p values) */
+    /* the corner indicator of the witch's-hat tests (WITCH descriptor only, bounds = its par):
+     * parallel (tests/temp-par-witch.R:52-59): k values, as.numeric(all(|theta_i| > bnd_i)) per component;
+     * serial (tests/temp-ser-witch.R:51-62): 2k values c(bar, baz), bar[i] = all(|theta| > bnd_i), baz[i] = 1 for
+     * the current component i, zeros elsewhere */
+    MCMCHIP_TOUT_WITCH_CORNER = 1
+};
+
 typedef struct mcmchip_temper_args {
     int64_t nens;
     int32_t ncomp;                   /* k >= 2 (temper.c:35-37) */
@@ -206,10 +216,13 @@ typedef struct mcmchip_temper_args {
     uint64_t seed, ens_offset, iter_offset;
     int32_t device_ptrs;
     int32_t debug;                   /* fill the debug trace (temper.c:282-464, vignettes/debug.Rnw:64-243) */
+    int32_t out_kind;                /* output functional (temper.c:977-988 evaluates an R closure): MCMCHIP_TOUT_* */
+    int32_t out_pad_;
 } mcmchip_temper_args;
 
 typedef struct mcmchip_temper_out {
-    double *batch;     /* parallel: nens x (nbatch x k x p), per ensemble batch[kb + nbatch*(i + k*j)] (temper.c:871-875);
+    double *batch;     /* out_kind != IDENTITY: nens x (nbatch x nout), per ensemble batch[kb + nbatch*j];
+                          parallel: nens x (nbatch x k x p), per ensemble batch[kb + nbatch*(i + k*j)] (temper.c:871-875);
                           serial:   nens x (nbatch x p),     per ensemble batch[kb + nbatch*j]       (temper.c:877-879) */
     double *ibatch;    /* serial only: nens x (nbatch x k), ibatch[kb + nbatch*i] (temper.c:881-886); may be NULL if parallel */
     double *acceptx;   /* nens x k ; 0/0 = NaN for a component never tried (temper.c:889-890) */

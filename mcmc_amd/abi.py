@@ -10,6 +10,7 @@ OK, EINVAL, EDOMAIN, EHIP, ECAP = 0, 1, 2, 3, 4
 T_LOGISTIC, T_LOGISTIC_NAIVE, T_MVNORM, T_NORMMIX = 1, 2, 3, 4
 T_SIMPLEX, T_BALL, T_WITCH, T_TEMPERED_NORMMIX = 5, 6, 7, 8
 T_STUDENT_T = 9
+TOUT_IDENTITY, TOUT_WITCH_CORNER = 0, 1
 T_LOGISTIC_MODELS = 10
 T_BINOMIAL_LOGIT = 11
 TEMPER_KINDS = (T_WITCH, T_TEMPERED_NORMMIX, T_LOGISTIC_MODELS)
@@ -104,6 +105,8 @@ class TemperArgs(C.Structure):
         ("iter_offset", C.c_uint64),
         ("device_ptrs", C.c_int32),
         ("debug", C.c_int32),
+        ("out_kind", C.c_int32),
+        ("out_pad_", C.c_int32),
     ]
 
 
@@ -339,7 +342,7 @@ class TemperCall:
     """numpy-backed argument/result block for one mcmchip_temper / orc_temper call"""
 
     def __init__(self, p, initial, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=RNG_PHILOX,
-                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None, debug=False):
+                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None, debug=False, out_kind=0):
         nb = np.asarray(neighbors)
         if nb.ndim != 2:
             raise ValueError('argument "neighbors" must be matrix')
@@ -370,6 +373,10 @@ class TemperCall:
         self.scale_kind, self.scale = classify_scale(scale, p, ncomp=k)
         self.unif, self.norm = _f64(unif), _f64(norm)
         E = self.nens
+        self.out_kind = int(out_kind)
+        if nout is None and self.out_kind == TOUT_WITCH_CORNER:
+            nout = k if self.parallel else 2 * k
+        self.identity_out = nout is None
         self.nout = nout if nout is not None else nstate - (0 if self.parallel else 1)
         self.batch = np.empty((E, self.nout, self.nbatch))       # per ensemble batch[kb + nbatch*i]
         self.ibatch = None if self.parallel else np.empty((E, k, self.nbatch))
@@ -391,7 +398,7 @@ class TemperCall:
         self.args = TemperArgs(E, k, int(self.parallel), self.nbatch, self.blen, self.nspac,
                                np_ptr(self.neighbors), np_ptr(self.initial), self.scale_kind,
                                np_ptr(self.scale), int(rng_mode), np_ptr(self.unif), np_ptr(self.norm),
-                               int(seed), int(ens_offset), int(iter_offset), 0, int(self.debug))
+                               int(seed), int(ens_offset), int(iter_offset), 0, int(self.debug), self.out_kind, 0)
         self.out = TemperOut(np_ptr(self.batch), np_ptr(self.ibatch), np_ptr(self.acceptx),
                              np_ptr(self.accepti), np_ptr(self.final), 0,
                              *[np_ptr(dbg.get(n)) for n in ("which", "unif_which", "state", "log_hastings",
@@ -402,7 +409,7 @@ class TemperCall:
         E, k, p = self.nens, self.k, self.p
         r = dict(acceptx=self.acceptx, accepti=np.transpose(self.accepti, (0, 2, 1)),
                  iter_offset=int(self.out.iter_offset_out))
-        if self.parallel and self.nout == k * p:
+        if self.parallel and self.identity_out:
             # per ensemble nbatch x k x p array, R layout batch[kb + nbatch*(i + k*j)]
             r["batch"] = np.transpose(self.batch.reshape(E, p, k, self.nbatch), (0, 3, 2, 1))
             r["final"] = np.transpose(self.final.reshape(E, p, k), (0, 2, 1))

@@ -284,7 +284,10 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
     initial  parallel: k x p matrix (or nens x k x p); serial: c(i, x) (or nens x (1+p))
     Returns the reference's names: lud, neighbors, nbatch, blen, nspac, scale, outfun, debug,
     parallel, initial.seed, final.seed, time, batch, acceptx, accepti, initial, final [, ibatch].
-    outfun functions are not available on the device path; debug = TRUE returns the reference's trace
+    outfun   None (identity, temper.c:851-867) or "witch.corner", the indicator functional of the reference's
+             witch's-hat tests (tests/temp-par-witch.R:52-59, temp-ser-witch.R:51-62); R closures cannot run on
+             the device.  A restart keeps the previous outfun when none is given (R/temper.R:16-18).
+    debug = TRUE returns the reference's trace
     (which, unif.which, state, log.hastings, unif.hastings, proposal, acceptd, norm, unif.choose[, coproposal]).
     """
     if isinstance(obj, dict):
@@ -298,6 +301,7 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
         scale = prev["scale"] if scale is None else scale
         parallel = prev["parallel"] if parallel is None else parallel
         debug = prev["debug"] if debug is None else debug
+        outfun = prev["outfun"] if outfun is None else outfun
         seed = prev["final.seed"][0] if seed is None else seed
         _iter_offset = prev["final.seed"][1]
         ens_offset = prev["final.seed"][2]
@@ -310,8 +314,14 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
     debug = False if debug is None else debug
     if not isinstance(target, Target) or not target.is_temper_kind:
         raise TypeError('argument "obj" must be a tempering Target or a previous result')
-    if outfun is not None:
+    if outfun is None:
+        out_kind = abi.TOUT_IDENTITY
+    elif outfun == "witch.corner":
+        out_kind = abi.TOUT_WITCH_CORNER
+    elif callable(outfun):
         raise NotImplementedError("temper: outfun functions cannot run on the device path")
+    else:
+        raise ValueError('argument "outfun" must be function or NULL')          # temper.c:68-69
     init_arr = np.asarray(initial, dtype=np.float64)
     single = init_arr.ndim == (2 if parallel else 1)
     if unif is not None or norm is not None:
@@ -322,7 +332,7 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
             seed = int.from_bytes(os.urandom(8), "little")
     call = abi.TemperCall(target.d, init_arr, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=mode,
                           unif=unif, norm=norm, seed=seed or 0, ens_offset=ens_offset,
-                          iter_offset=_iter_offset, debug=debug)
+                          iter_offset=_iter_offset, debug=debug, out_kind=out_kind)
     t0 = time.perf_counter()
     _check(load_library().mcmchip_temper(target.handle, C.addressof(call.args), C.addressof(call.out)))
     elapsed = time.perf_counter() - t0
@@ -332,7 +342,7 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
         return a[0] if single else a
 
     out = {"lud": target, "neighbors": np.asarray(neighbors, dtype=bool), "nbatch": int(nbatch),
-           "blen": int(blen), "nspac": int(nspac), "scale": scale, "outfun": None, "debug": bool(debug),
+           "blen": int(blen), "nspac": int(nspac), "scale": scale, "outfun": outfun, "debug": bool(debug),
            "parallel": bool(parallel), "initial.seed": (seed, _iter_offset, ens_offset),
            "final.seed": (seed, r["iter_offset"], ens_offset), "time": elapsed,
            "batch": sq(r["batch"]), "acceptx": sq(r["acceptx"]), "accepti": sq(r["accepti"]),

@@ -63,6 +63,7 @@ struct TemperDev {
     unsigned long long seed, ens_offset, iter_offset;
     double *batch, *ibatch, *acceptx, *accepti, *final_;
     int debug;
+    int out_kind;             // MCMCHIP_TOUT_*
     int *dbg_which, *dbg_acceptd;
     double *dbg_unif_which, *dbg_state, *dbg_lh, *dbg_uh, *dbg_proposal, *dbg_norm, *dbg_unif_choose, *dbg_coproposal;
     int *flag;

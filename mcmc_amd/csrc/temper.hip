@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     const long e = blockIdx.x;
     const int k = q.k, p = q.p, par = q.parallel;
     const int nstate = par ? k * p : p + 1;
-    const int nout = par ? k * p : p;
+    const int corner = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER;
+    const int nout = corner ? (par ? k : 2 * k) : (par ? k * p : p);
     double *S = lds + lay.state, *L = lds + lay.L, *Y = lds + lay.Y, *Z = lds + lay.Z;
     double *buf = lds + lay.buf, *ibuf = lds + lay.ibuf;
     unsigned *axn = (unsigned *)(lds + lay.axn), *axd = (unsigned *)(lds + lay.axd);
@@ -281,7 +282,23 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                 __syncthreads();
             }
             // batch accumulation once per blen step (temper.c:851-867)
-            for (int i = lane; i < nout; i += 64) buf[i] += par ? S[i] : S[i + 1];
+            if (!corner) {
+                for (int i = lane; i < nout; i += 64) buf[i] += par ? S[i] : S[i + 1];
+            } else if (par) {                   // tests/temp-par-witch.R:52-59
+                for (int i = lane; i < k; i += 64) {
+                    bool all = true;
+                    for (int j = 0; j < p; j++) all &= fabs(S[i + k * j]) - q.par[i] > 0;
+                    buf[i] += all ? 1.0 : 0.0;
+                }
+            } else {                            // tests/temp-ser-witch.R:51-62: c(bar, baz)
+                const int ic = (int)S[0];
+                bool all = true;
+                for (int j = 0; j < p; j++) all &= fabs(S[1 + j]) > q.par[ic - 1];
+                for (int i = lane; i < 2 * k; i += 64) {
+                    const int comp = i < k ? i : i - k;
+                    buf[i] += (comp == ic - 1) ? (i < k ? (all ? 1.0 : 0.0) : 1.0) : 0.0;
+                }
+            }
             if (!par && lane == 0) ibuf[(int)S[0] - 1] += 1.0;
         }
         __syncthreads();
@@ -328,7 +345,7 @@ int launch_temper(const TemperDev &q, hipStream_t s)
         maxnn = m;
     }
     const int nstate = q.parallel ? k * p : p + 1;
-    const int nout = q.parallel ? k * p : p;
+    const int nout = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (q.parallel ? k : 2 * k) : (q.parallel ? k * p : p);
     TemperLds lay;
     int o = 0;
     lay.state = o; o += nstate;

@@ -751,3 +751,128 @@ def test_olbm_time_sharding_arithmetic_on_device(api, oracle_mod):
     got = total / (float(n - blen + 1) * n * blen)
     ref, _ = oracle_mod.olbm(x, blen)
     assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))
+
+
+def _inject_from_trace(ref, parallel, p):
+    """random numbers of an oracle run (driven by the emulated R stream) laid out as the device's injected slots
+    unif[iter][4] = {which, choose1, choose2, hastings}, norm[iter][p]; slots the run did not draw are never read"""
+    T = ref["unif.which"].shape[1]
+    unif = np.full((1, T, 4), 0.5)
+    unif[0, :, 0] = ref["unif.which"][0]
+    uc = ref["unif.choose"][0]
+    if parallel:
+        unif[0, :, 1] = np.where(np.isnan(uc[:, 0]), 0.5, uc[:, 0])
+        unif[0, :, 2] = np.where(np.isnan(uc[:, 1]), 0.5, uc[:, 1])
+    else:
+        unif[0, :, 1] = np.where(np.isnan(uc), 0.5, uc)
+    uh = ref["unif.hastings"][0]
+    unif[0, :, 3] = np.where(np.isnan(uh), 0.5, uh)
+    norm = np.where(np.isnan(ref["norm"][0]), 0.0, ref["norm"][0]).reshape(1, T, p)
+    return unif, norm
+
+
+def test_temper_device_reproduces_reference_transcripts(api, oracle_mod):
+    """tests/temp-par-witch.Rout.save and tests/temp-ser-witch.Rout.save on the DEVICE: the oracle, driven by the
+    emulated R stream (set.seed(42)), records which uniforms/normals each iteration drew; the device replays them
+    as injected streams, with the reference's outfun (corner indicator) where the script uses one, and must print
+    the transcript's numbers."""
+    from test_oracle_golden import WITCH, _witch_neighbors
+    nb = _witch_neighbors()
+    sc = 0.3456789
+    ot, dt = oracle_mod.Target(abi.T_WITCH, 3, par=WITCH), api.Target(abi.T_WITCH, 3, par=WITCH)
+    # ---- parallel (temp-par-witch.R:42-75)
+    rs = oracle_mod.RStream(42)
+    runs = [(50, 13, None), (50, 13, "witch.corner"), (50, 103, "witch.corner")]
+    state = np.zeros((6, 3))
+    outs = []
+    for nbatch, blen, outfun in runs:
+        ref = oracle_mod.temper(ot, state, nb, nbatch, blen, 7, sc, parallel=True, rstream=rs, debug=True,
+                                out_kind=oracle_mod.TOUT_WITCH_PAR if outfun else oracle_mod.TOUT_NONE)
+        unif, norm = _inject_from_trace(ref, True, 3)
+        o = api.temper(dt, state[None], nb, nbatch, blen, 7, sc, parallel=True, unif=unif, norm=norm, outfun=outfun)
+        assert np.array_equal(o["final"][0], ref["final"][0])
+        assert np.allclose(o["batch"][0], ref["batch"][0], rtol=1e-14, atol=1e-15)
+        state = ref["final"][0]
+        outs.append(o)
+    assert list(np.round(outs[0]["acceptx"][0], 4)) == [0.6336, 0.4974, 0.3245, 0.6022, 0.6130, 0.5914]
+    b = outs[1]["batch"][0]
+    assert b.shape == (50, 6)
+    assert np.allclose(b.mean(axis=0), [0.54923, 0.40923, 0.39538, 0.09692, 0.12923, 0.60000], atol=5e-6)
+    assert np.allclose(b.std(axis=0, ddof=1) / np.sqrt(50), [0.03482, 0.04817, 0.05464, 0.02856, 0.02113, 0.05131], atol=5e-6)
+    b = outs[2]["batch"][0]
+    assert np.allclose(b.mean(axis=0), [0.5231, 0.5361, 0.4905, 0.5652, 0.4056, 0.2450], atol=5e-5)
+    # ---- serial (temp-ser-witch.R:36-78)
+    rs = oracle_mod.RStream(42)
+    state = np.array([1.0, 0, 0, 0])
+    ref = oracle_mod.temper(ot, state, nb, 50, 13, 7, sc, parallel=False, rstream=rs, debug=True)
+    unif, norm = _inject_from_trace(ref, False, 3)
+    o = api.temper(dt, state[None], nb, 50, 13, 7, sc, parallel=False, unif=unif, norm=norm)
+    assert np.allclose(o["acceptx"][0], [0.6388889, 0.4385246, 0.3631714, 0.4885246, 0.4709677, 0.4735516], atol=5e-8)
+    assert np.allclose(o["ibatch"][0].mean(axis=0), [0.1830769, 0.2153846, 0.1630769, 0.1369231, 0.1353846, 0.1661538], atol=5e-8)
+    ref2 = oracle_mod.temper(ot, ref["final"][0], nb, 50, 103, 7, sc, parallel=False, rstream=rs, debug=True,
+                             out_kind=oracle_mod.TOUT_WITCH_SER)
+    unif, norm = _inject_from_trace(ref2, False, 3)
+    o2 = api.temper(dt, ref["final"][0][None], nb, 50, 103, 7, sc, parallel=False, unif=unif, norm=norm,
+                    outfun="witch.corner")
+    b = o2["batch"][0]
+    assert b.shape == (50, 12)
+    eta, noo = b[:, :6].mean(axis=0), b[:, 6:].mean(axis=0)
+    assert np.allclose(eta, [0.06660194, 0.06388350, 0.05766990, 0.06563107, 0.10368932, 0.22912621], atol=5e-9)
+    assert np.allclose(noo, [0.1365049, 0.1258252, 0.1293204, 0.1370874, 0.1716505, 0.2996117], atol=5e-8)
+    assert np.allclose(eta / noo, [0.4879090, 0.5077160, 0.4459459, 0.4787535, 0.6040724, 0.7647440], atol=5e-8)
+    with pytest.raises(api.McmcHipError, match="witch"):
+        api.temper(api.Target(abi.T_TEMPERED_NORMMIX, 2, par=np.concatenate([[2.0], [1.0, 0.5], abi.normmix_par([1.0], [[0.0, 0.0]], 1.0)])),
+                   np.zeros((2, 2)), np.array([[0, 1], [1, 0]], dtype=bool), 3, 1, 1, 0.5, parallel=True, seed=1, outfun="witch.corner")
+
+
+def _replay_metrop(api, oracle_mod, dtg, otg, x0, nbatch, blen, scale, rs):
+    """one metrop call of a reference script: the oracle consumes the emulated R stream and records the normals and
+    uniforms it drew (debug trace); the device replays them as injected streams"""
+    ref = oracle_mod.metrop(otg, x0, nbatch, blen, scale=scale, rstream=rs, debug=True)
+    z = ref["z"]                                           # (1, niter, d)
+    u = np.where(np.isnan(ref["u"]), 0.5, ref["u"])        # undrawn slots are never read
+    o = api.metrop(dtg, np.asarray(x0, dtype=np.float64)[None], nbatch, blen, scale=scale, z=z, u=u)
+    assert np.array_equal(o["final"][0], ref["final"][0])
+    return o, ref
+
+
+def test_metrop_device_reproduces_reference_transcripts(api, oracle_mod):
+    """tests/logit.Rout.save (with its olbm matrix), tests/accept-batch.Rout.save and tests/circle.Rout.save printed
+    by the DEVICE path: random numbers as R would have drawn them (emulated stream, replayed as injected)."""
+    from rhelpers import signif, t_conf_int
+    # ---- tests/logit.R (Marsaglia-Multicarry; data simulated in the script; naive log likelihood)
+    rs = oracle_mod.RStream(42, "Marsaglia-Multicarry")
+    n, rho = 100, 0.5
+    x1 = rs.rnorm(n)
+    x2 = rho * x1 + np.sqrt(1 - rho ** 2) * rs.rnorm(n)
+    eta = 0.25 + 1 * x1 + 0.5 * x2
+    y = (rs.runif(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    X = np.column_stack([np.ones(n), x1, x2])
+    coef = glm_binomial(X, y)
+    kw = dict(x=X, y=y, prior_c=0.0)
+    dtg, otg = api.Target(abi.T_LOGISTIC_NAIVE, 3, **kw), oracle_mod.Target(abi.T_LOGISTIC_NAIVE, 3, **kw)
+    assert round(-api.logdens(dtg, coef[None])[0], 1) == 49.6                     # logit.Rout.save:83
+    x = coef
+    for sc, expect in [(0.01, 0.982), (0.1, 0.795), (0.5, 0.264)]:               # :104-112
+        o, ref = _replay_metrop(api, oracle_mod, dtg, otg, x, 1000, 1, sc, rs)
+        assert o["accept"][0] == expect
+        x = ref["final"][0]
+    b = o["batch"][0]
+    assert list(np.round(b.mean(axis=0), 4)) == [0.0608, 1.4230, 0.5263]         # :115
+    var = api.olbm(b, 25)                                                        # :121-125, on the device
+    assert np.allclose(signif(var, 3), [[4.54e-04, 9.47e-05, -1.92e-05], [9.47e-05, 1.84e-03, -6.45e-04],
+                                        [-1.92e-05, -6.45e-04, 9.09e-04]], rtol=1e-12)
+    # ---- tests/accept-batch.R
+    h_d, h_o = api.Target(abi.T_SIMPLEX, 5, par=[1.0]), oracle_mod.Target(abi.T_SIMPLEX, 5, par=[1.0])
+    o, _ = _replay_metrop(api, oracle_mod, h_d, h_o, np.zeros(5), 100, 100, 0.1, oracle_mod.RStream(42))
+    assert round(o["accept"][0], 4) == 0.2257                                    # accept-batch.Rout.save:33
+    lo, hi = t_conf_int(o["accept.batch"][0])
+    assert (round(lo, 4), round(hi, 4)) == (0.2124, 0.2390)                      # :39-42
+    # ---- tests/circle.R (Marsaglia-Multicarry)
+    rs = oracle_mod.RStream(42, "Marsaglia-Multicarry")
+    c_d, c_o = api.Target(abi.T_BALL, 5), oracle_mod.Target(abi.T_BALL, 5)
+    x = np.zeros(5)
+    for sc, expect in [(0.01, 0.979), (0.1, 0.72), (0.5, 0.16), (0.4, 0.228)]:   # circle.Rout.save:24-50
+        o, ref = _replay_metrop(api, oracle_mod, c_d, c_o, x, 1000, 1, sc, rs)
+        assert o["accept"][0] == expect
+        x = ref["final"][0]
