@@ -27,6 +27,15 @@ struct StreamLayout {
     size_t lds_bytes;
 };
 
+// The G lanes that own a chain sit in one wavefront and LDS operations of a wavefront complete in order, so the
+// chain's private LDS buffers need no workgroup barrier inside the iteration loop: a wavefront-scope fence keeps
+// the compiler from moving LDS accesses across the hand-over points.
+#define CHAIN_SYNC()                                             \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
 template <int G>
 __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamLayout lay)
 {
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
                         if (2 * j2 + 1 < d) Z[2 * j2 + 1] = zb;
                     }
                 }
-                if (p.scale_kind == MCMCHIP_SCALE_FULL) __syncthreads();
+                if (p.scale_kind == MCMCHIP_SCALE_FULL) CHAIN_SYNC();
                 // ---- proposal (metrop.c:380-403)
                 if (p.scale_kind == MCMCHIP_SCALE_CONSTANT) {
                     const double s0 = p.scale[0];
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
                         Y[j] = a;
                     }
                 }
-                __syncthreads();
+                CHAIN_SYNC();
                 // ---- log density of the proposal (logh(), metrop.c:223)
                 const double ly = lud_morphed_group<G>(tv, Y, W, g);
                 if (ly == INFINITY || isnan(ly)) {
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
                     acc += 1.0; acc_b += 1.0;
                 }
                 tries += 1.0; tries_b += 1.0;
-                __syncthreads();
+                CHAIN_SYNC();
             }
             // ---- outfun + batch accumulation, once per blen step (metrop.c:273-275)
             const double *S = X;
