@@ -77,12 +77,15 @@ template <int G> __device__ double lud_group(const TargetView &t, const double *
         // vignettes/demo.Rnw:59-65; eta accumulated j-ascending with separately rounded
         // multiply and add, like the reference's x %*% beta
         double lp = 0.0, lq = 0.0, ss = 0.0;
+#pragma unroll 4
         for (long i = g; i < t.n; i += G) {
             const double *xi = t.x + (size_t)i * d;
             double eta = 0.0;
             for (int j = 0; j < d; j++) eta = add_nofma(eta, mul_nofma(xi[j], v[j]));
-            if (t.y[i] == 1.0) lp += (eta < 0) ? eta - log1p(exp(eta)) : -log1p(exp(-eta));
-            else lq += (eta < 0) ? -log1p(exp(eta)) : -eta - log1p(exp(-eta));
+            // branch-free form of the reference's ifelse (vignettes/demo.Rnw:61-62): same operations per branch
+            const double l1 = log1p(exp(-fabs(eta)));
+            if (t.y[i] == 1.0) lp += (eta < 0) ? eta - l1 : -l1;
+            else lq += (eta < 0) ? -l1 : -eta - l1;
         }
         for (int j = g; j < d; j += G) ss += v[j] * v[j];
         lp = group_sum<G>(lp);
@@ -252,12 +255,14 @@ __device__ double lud_models_group(const double *par, int p, const double *x, co
     const int k = (int)par[0];
     const double *mask = par + 1 + (size_t)(i - 1) * p, *lpp = par + 1 + (size_t)k * p;
     double lp = 0.0, lq = 0.0;
+#pragma unroll 2
     for (long r = g; r < n; r += G) {
         const double *xi = x + (size_t)r * p;
         double eta = 0.0;
         for (int j = 0; j < p; j++) eta = add_nofma(eta, mul_nofma(xi[j], mask[j] != 0 ? th[j] : 0.0));
-        if (y[r] == 1.0) lp += (eta < 0) ? eta - log1p(exp(eta)) : -log1p(exp(-eta));
-        else lq += (eta < 0) ? -log1p(exp(eta)) : -eta - log1p(exp(-eta));
+        const double l1 = log1p(exp(-fabs(eta)));      // the reference's ifelse, branch-free (same operations)
+        if (y[r] == 1.0) lp += (eta < 0) ? eta - l1 : -l1;
+        else lq += (eta < 0) ? -l1 : -eta - l1;
     }
     lp = group_sum<G>(lp);
     lq = group_sum<G>(lq);
