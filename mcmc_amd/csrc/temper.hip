@@ -27,7 +27,9 @@
 #define TEMPER_MAXK 64
 
 struct TemperLds {
-    int state, L, Y, Z, buf, ibuf, axn, axd, ain, aid, nn, nb, ubuf, zbuf, end;  // offsets in 8-byte words
+    int state, L, Y, Z, buf, ibuf, axn, axd, ain, aid, nn, nb, ubuf, zbuf, par, scale, end;  // offsets in 8-byte words
+    int npar_lds, nscale_lds;     // > 0: the descriptor parameters / the scale are staged in LDS (the serial chain of
+                                  // an iteration then never waits on global memory)
 };
 
 __device__ __forceinline__ int pick1(double u, int m)
@@ -54,12 +56,23 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     double *Ubuf = lds + lay.ubuf, *Zbuf = lds + lay.zbuf;   // Philox draws of the next 64 iterations
     const int pz = (p + 1) & ~1;
 
+    const double *gpar = q.par, *gscale = q.scale;
+    if (lay.npar_lds > 0) {
+        double *lp = lds + lay.par;
+        for (int i = lane; i < lay.npar_lds; i += 64) lp[i] = q.par[i];
+        gpar = lp;
+    }
+    if (lay.nscale_lds > 0) {
+        double *ls = lds + lay.scale;
+        for (int i = lane; i < lay.nscale_lds; i += 64) ls[i] = q.scale[i];
+        gscale = ls;
+    }
     // log density of (component comp, theta): called with wave-uniform arguments only.  The data-carrying
     // kind spreads its observations over the 64 lanes; the small closed-form kinds are scalar per lane.
     const bool coop = q.kind == MCMCHIP_T_LOGISTIC_MODELS;
     auto LUD = [&](int comp, const double *th) -> double {
-        if (coop) return lud_models_group<64>(q.par, p, q.x, q.y, q.n, q.prior_c, comp, th, lane);
-        return lud_temper(q.kind, p, q.par, k, comp, th);
+        if (coop) return lud_models_group<64>(gpar, p, q.x, q.y, q.n, q.prior_c, comp, th, lane);
+        return lud_temper(q.kind, p, gpar, k, comp, th);
     };
 
     for (int i = lane; i < nstate; i += 64) S[i] = q.initial[(size_t)e * nstate + i];
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
         for (int i = lane; i < k; i += 64) {
             double th[TEMPER_MAXP];
             for (int j = 0; j < p; j++) th[j] = S[i + k * j];
-            double v = lud_temper(q.kind, p, q.par, k, i + 1, th);
+            double v = lud_temper(q.kind, p, gpar, k, i + 1, th);
             L[i] = v;
             if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
             else if (v == INFINITY) atomicOr(q.flag, FLAG_POSINF);
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
         __syncthreads();
         {
             const int i = (int)S[0];
-            const double v = coop ? LUD(i, S + 1) : (lane == 0 ? lud_temper(q.kind, p, q.par, k, i, S + 1) : 0.0);
+            const double v = coop ? LUD(i, S + 1) : (lane == 0 ? lud_temper(q.kind, p, gpar, k, i, S + 1) : 0.0);
             if (lane == 0) {
                 L[i - 1] = v;
                 if (v == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                 }
                 const bool within = u0 < 0.5;          // temper.c:537-538
                 double lh;
-                int ci, cj = 0;                        // 1-based components
+                int ci, cj = 0, slot_ = 0;             // 1-based components; slot_ = position of cj among ci's neighbours
                 double ly = 0.0, sco = 0.0, spr = 0.0;
                 if (within) {
                     ci = par ? pick1(u1, k) : (int)S[0];
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                         for (int j = lane; j < p; j += 64) Z[j] = Zbuf[(it & 63) * pz + j];
                     }
                     __syncthreads();
-                    const double *sc = q.scale + (slist ? (size_t)(ci - 1) * slen1 : 0);
+                    const double *sc = gscale + (slist ? (size_t)(ci - 1) * slen1 : 0);
                     for (int j = lane; j < p; j += 64) {
                         const double xj = par ? S[(ci - 1) + k * j] : S[1 + j];
                         double yj;
@@ -200,9 +213,12 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                 } else if (par) {
                     u2 = up[2];
                     ci = pick1(u1, k);
-                    cj = nb[(ci - 1) * maxnn + pick1(u2, nn[ci - 1]) - 1] + 1;
-                    double xi[TEMPER_MAXP], xj[TEMPER_MAXP];
-                    for (int j = 0; j < p; j++) { xi[j] = S[(ci - 1) + k * j]; xj[j] = S[(cj - 1) + k * j]; }
+                    slot_ = pick1(u2, nn[ci - 1]) - 1;
+                    cj = nb[(ci - 1) * maxnn + slot_] + 1;
+                    // the two rows go through the LDS buffers Y (x_i) and Z (x_j): no private arrays
+                    for (int j = lane; j < p; j += 64) { Y[j] = S[(ci - 1) + k * j]; Z[j] = S[(cj - 1) + k * j]; }
+                    __syncthreads();
+                    const double *xi = Y, *xj = Z;
                     sco = LUD(cj, xi);   // (j, x_i) first (temper.c:738-739)
                     spr = LUD(ci, xj);   // (i, x_j)
                     lh = spr + sco - L[cj - 1] - L[ci - 1];       // temper.c:742-744
@@ -222,7 +238,8 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (lane == 0) atomicOr(q.flag, FLAG_NAN); }
                 } else {
                     ci = (int)S[0];
-                    cj = nb[(ci - 1) * maxnn + pick1(u1, nn[ci - 1]) - 1] + 1;
+                    slot_ = pick1(u1, nn[ci - 1]) - 1;
+                    cj = nb[(ci - 1) * maxnn + slot_] + 1;
                     ly = LUD(cj, S + 1);
                     lh = ly - L[ci - 1] + log((double)nn[ci - 1]) - log((double)nn[cj - 1]);   // temper.c:810-812
                     if (q.debug) {   // temper.c:825-835
@@ -266,17 +283,13 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                         if (lane == 0) { L[ci - 1] = spr; L[cj - 1] = sco; }
                     }
                     if (lane == 0) {
-                        int slot = 0;
-                        while (nb[(ci - 1) * maxnn + slot] != cj - 1) slot++;
-                        if (accept) ain[(ci - 1) * maxnn + slot]++;
-                        aid[(ci - 1) * maxnn + slot]++;
+                        if (accept) ain[(ci - 1) * maxnn + slot_]++;
+                        aid[(ci - 1) * maxnn + slot_]++;
                     }
                 } else {
                     if (lane == 0) {
-                        int slot = 0;
-                        while (nb[(ci - 1) * maxnn + slot] != cj - 1) slot++;
-                        if (accept) { S[0] = cj; L[cj - 1] = ly; ain[(ci - 1) * maxnn + slot]++; }
-                        aid[(ci - 1) * maxnn + slot]++;
+                        if (accept) { S[0] = cj; L[cj - 1] = ly; ain[(ci - 1) * maxnn + slot_]++; }
+                        aid[(ci - 1) * maxnn + slot_]++;
                     }
                 }
                 __syncthreads();
@@ -287,13 +300,13 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
             } else if (par) {                   // tests/temp-par-witch.R:52-59
                 for (int i = lane; i < k; i += 64) {
                     bool all = true;
-                    for (int j = 0; j < p; j++) all &= fabs(S[i + k * j]) - q.par[i] > 0;
+                    for (int j = 0; j < p; j++) all &= fabs(S[i + k * j]) - gpar[i] > 0;
                     buf[i] += all ? 1.0 : 0.0;
                 }
             } else {                            // tests/temp-ser-witch.R:51-62: c(bar, baz)
                 const int ic = (int)S[0];
                 bool all = true;
-                for (int j = 0; j < p; j++) all &= fabs(S[1 + j]) > q.par[ic - 1];
+                for (int j = 0; j < p; j++) all &= fabs(S[1 + j]) > gpar[ic - 1];
                 for (int i = lane; i < 2 * k; i += 64) {
                     const int comp = i < k ? i : i - k;
                     buf[i] += (comp == ic - 1) ? (i < k ? (all ? 1.0 : 0.0) : 1.0) : 0.0;
@@ -362,6 +375,14 @@ int launch_temper(const TemperDev &q, hipStream_t s)
     lay.nb = o; o += (k * maxnn + 1) / 2;
     lay.ubuf = o; o += 64 * 4;
     lay.zbuf = o; o += 64 * ((p + 1) & ~1);
+    // descriptor parameters and scale: into LDS when small (they are read inside the serial chain)
+    const long npar_dev = q.kind == MCMCHIP_T_WITCH ? 3L * k : q.npar;
+    const long slen1h = (q.scale_kind & 7) == MCMCHIP_SCALE_CONSTANT ? 1 : ((q.scale_kind & 7) == MCMCHIP_SCALE_DIAGONAL ? p : p * p);
+    const long nscale = (q.scale_kind & MCMCHIP_SCALE_LIST) ? slen1h * k : slen1h;
+    lay.npar_lds = (npar_dev > 0 && npar_dev <= 2048) ? (int)npar_dev : 0;
+    lay.nscale_lds = nscale <= 1024 ? (int)nscale : 0;
+    lay.par = o; o += lay.npar_lds;
+    lay.scale = o; o += lay.nscale_lds;
     lay.end = o;
     size_t bytes = (size_t)o * 8;
     if (bytes > 64 * 1024) return set_error(MCMCHIP_EINVAL, "tempering state (%zu bytes) does not fit the LDS budget", bytes);
