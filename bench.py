@@ -48,7 +48,7 @@ def cpu_baseline(X, y, beta, scale, threads, budget_s=12.0):
     t0 = time.perf_counter()
     oracle.metrop(tg, init, 1, scale=scale, seed=1, nthreads=threads)      # 2 density evaluations per chain
     per_eval = (time.perf_counter() - t0) / 2.0
-    iters = int(max(2, min(40, budget_s / max(per_eval, 1e-6) - 1)))
+    iters = int(max(2, min(1000, budget_s / max(per_eval, 1e-6) - 1)))
     t0 = time.perf_counter()
     oracle.metrop(tg, init, iters, scale=scale, seed=1, nthreads=threads)
     el = time.perf_counter() - t0
