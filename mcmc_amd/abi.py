@@ -19,6 +19,7 @@ SCALE_CONSTANT, SCALE_DIAGONAL, SCALE_FULL, SCALE_LIST = 1, 2, 3, 8
 OUT_IDENTITY, OUT_INDEX, OUT_MOMENTS2 = 0, 1, 2
 RNG_INJECTED, RNG_PHILOX = 1, 2
 PATH_AUTO, PATH_STREAM, PATH_MFMA = 0, 1, 2
+PATH_LDS, PATH_REG = 1, 2      # temper kernels (mcmchip_temper_args.path)
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -106,7 +107,7 @@ class TemperArgs(C.Structure):
         ("device_ptrs", C.c_int32),
         ("debug", C.c_int32),
         ("out_kind", C.c_int32),
-        ("out_pad_", C.c_int32),
+        ("path", C.c_int32),
     ]
 
 
@@ -342,7 +343,7 @@ class TemperCall:
     """numpy-backed argument/result block for one mcmchip_temper / orc_temper call"""
 
     def __init__(self, p, initial, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=RNG_PHILOX,
-                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None, debug=False, out_kind=0):
+                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None, debug=False, out_kind=0, path=0):
         nb = np.asarray(neighbors)
         if nb.ndim != 2:
             raise ValueError('argument "neighbors" must be matrix')
@@ -398,7 +399,7 @@ class TemperCall:
         self.args = TemperArgs(E, k, int(self.parallel), self.nbatch, self.blen, self.nspac,
                                np_ptr(self.neighbors), np_ptr(self.initial), self.scale_kind,
                                np_ptr(self.scale), int(rng_mode), np_ptr(self.unif), np_ptr(self.norm),
-                               int(seed), int(ens_offset), int(iter_offset), 0, int(self.debug), self.out_kind, 0)
+                               int(seed), int(ens_offset), int(iter_offset), 0, int(self.debug), self.out_kind, int(path))
         self.out = TemperOut(np_ptr(self.batch), np_ptr(self.ibatch), np_ptr(self.acceptx),
                              np_ptr(self.accepti), np_ptr(self.final), 0,
                              *[np_ptr(dbg.get(n)) for n in ("which", "unif_which", "state", "log_hastings",

@@ -277,7 +277,7 @@ def morph_metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=No
 
 
 def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None, scale=None, outfun=None,
-           debug=None, parallel=None, seed=None, unif=None, norm=None, ens_offset=0, _iter_offset=0):
+           debug=None, parallel=None, seed=None, unif=None, norm=None, ens_offset=0, _iter_offset=0, _path=0):
     """temper(obj, initial, neighbors, nbatch, blen = 1, nspac = 1, scale = 1, outfun,
               debug = FALSE, parallel = FALSE)   -- R/temper.R:2-75
 
@@ -332,7 +332,7 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
             seed = int.from_bytes(os.urandom(8), "little")
     call = abi.TemperCall(target.d, init_arr, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=mode,
                           unif=unif, norm=norm, seed=seed or 0, ens_offset=ens_offset,
-                          iter_offset=_iter_offset, debug=debug, out_kind=out_kind)
+                          iter_offset=_iter_offset, debug=debug, out_kind=out_kind, path=_path)
     t0 = time.perf_counter()
     _check(load_library().mcmchip_temper(target.handle, C.addressof(call.args), C.addressof(call.out)))
     elapsed = time.perf_counter() - t0

@@ -454,6 +454,8 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
         return set_error(MCMCHIP_EINVAL, "argument \"outfun\" must be function or NULL");     // temper.c:68-69
     if (a->out_kind == MCMCHIP_TOUT_WITCH_CORNER && t->kind != MCMCHIP_T_WITCH)
         return set_error(MCMCHIP_EINVAL, "the corner-indicator output functional belongs to the witch's hat descriptor");
+    if (a->path != MCMCHIP_PATH_AUTO && a->path != MCMCHIP_PATH_LDS && a->path != MCMCHIP_PATH_REG)
+        return set_error(MCMCHIP_EINVAL, "unknown temper path %d", a->path);
     const int nout = a->out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (a->parallel ? k : 2 * k) : (a->parallel ? k * p : p);
     InBuf init, scale, nbrs, unif, norm;
     OutBuf batch, ibatch, acceptx, accepti, final_;
@@ -498,6 +500,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     q.accepti = accepti.as<double>(); q.final_ = final_.as<double>();
     q.debug = a->debug;
     q.out_kind = a->out_kind;
+    q.path = a->path;
     q.dbg_which = dwhich.as<int>(); q.dbg_acceptd = dacc.as<int>(); q.dbg_unif_which = duw.as<double>();
     q.dbg_state = dstate.as<double>(); q.dbg_lh = dlh.as<double>(); q.dbg_uh = duh.as<double>();
     q.dbg_proposal = dprop.as<double>(); q.dbg_norm = dnorm.as<double>(); q.dbg_unif_choose = duc.as<double>();

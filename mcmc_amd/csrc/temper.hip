@@ -336,6 +336,290 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     for (int i = lane; i < nstate; i += 64) q.final_[(size_t)e * nstate + i] = S[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident variant for the common shape of parallel tempering: k <= 64 components of dimension
+// P <= 4 with closed-form densities (C4: 64 temperatures, witch's hat p = 3 / tempered mixture p = 2).
+// Lane c of the ensemble's wavefront OWNS component c: its state x[P], its cached log density
+// (temper.c:123-124), its batch accumulator and its within-acceptance counters are registers of that
+// lane.  The elementary update is wave-uniform: the chosen component's row is fetched with v_readlane
+// (no LDS round trip), the proposal / density / Hastings ratio are evaluated redundantly by all lanes,
+// and the accepted row is written back with a lane-predicated move; a swap (temper.c:679-781) is two
+// readlanes and two predicated moves, its two densities evaluated side by side on the two half-waves.
+// Random numbers of iteration it+1 are fetched while iteration it runs.  Same draw order, same Philox
+// counters and the same arithmetic as temper_kernel: results are bitwise the same (tested).
+struct TemperRegLds {
+    int ubuf, zbuf, ain, aid, par, scale, end;   // offsets in 8-byte words
+    int npar_lds, nscale_lds;
+};
+
+__device__ __forceinline__ double lane_read(double v, int l)     // l wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+template <int P> __device__ __forceinline__ double witch_value(double bnd, double inside, double cornerv, const double *th)
+{
+    bool out = false, all = true;                  // same tests as lud_temper's WITCH case
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const double a = fabs(th[j]);
+        out |= a > 1.0;
+        all &= a > bnd;
+    }
+    return out ? -INFINITY : (all ? cornerv : inside);
+}
+
+template <int P, int KIND>
+__global__ __launch_bounds__(64) void temper_reg_kernel(TemperDev q, TemperRegLds lay, int maxnn)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long e = blockIdx.x;
+    const int k = q.k;
+    constexpr int PZ = (P + 1) & ~1;
+    constexpr bool WITCH = KIND == MCMCHIP_T_WITCH;
+    const bool corner = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER;
+    const int nout = corner ? k : k * P;
+    double *Ubuf = lds + lay.ubuf, *Zbuf = lds + lay.zbuf;
+    unsigned *ain = (unsigned *)(lds + lay.ain), *aid = (unsigned *)(lds + lay.aid);
+    const double *gpar = q.par, *gscale = q.scale;
+    if (lay.npar_lds > 0) {
+        double *lp = lds + lay.par;
+        for (int i = lane; i < lay.npar_lds; i += 64) lp[i] = q.par[i];
+        gpar = lp;
+    }
+    if (lay.nscale_lds > 0) {
+        double *ls = lds + lay.scale;
+        for (int i = lane; i < lay.nscale_lds; i += 64) ls[i] = q.scale[i];
+        gscale = ls;
+    }
+    for (int i = lane; i < k * maxnn; i += 64) ain[i] = aid[i] = 0;
+    const bool live = lane < k;
+    const int c = live ? lane : 0;                 // idle lanes shadow component 0 and never write
+    const int sk = q.scale_kind & 7;
+    const bool slist = (q.scale_kind & MCMCHIP_SCALE_LIST) != 0;
+    const bool inj = q.rng_mode == MCMCHIP_RNG_INJECTED;
+
+    double x[P], acc[P], sc[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        x[j] = q.initial[(size_t)e * k * P + c + k * j];
+        acc[j] = 0.0;
+        // constant scale = diagonal scale with equal entries (same multiply, same add)
+        sc[j] = sk == MCMCHIP_SCALE_CONSTANT ? q.scale[slist ? c : 0]
+              : sk == MCMCHIP_SCALE_DIAGONAL ? q.scale[(slist ? c * P : 0) + j] : 0.0;
+    }
+    int nn = 0;
+    unsigned long long nbp = 0;                    // neighbours of component c, ascending (temper.c:504-510), 8 bits each
+    for (int j = 0; j < k; j++)
+        if (q.neighbors[c + k * j]) { nbp |= (unsigned long long)j << (8 * nn); nn++; }
+    unsigned axn = 0, axd = 0;
+    double wb = 0.0, win = 0.0, wco = 0.0;
+    if (WITCH) { wb = q.par[c]; win = q.par[k + c]; wco = q.par[2 * k + c]; }
+    __syncthreads();
+
+    double L = WITCH ? witch_value<P>(wb, win, wco, x) : lud_temper(KIND, P, gpar, k, c + 1, x);   // temper.c:98-119
+    if (live) {
+        if (L == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+        else if (L == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+        else if (isnan(L)) atomicOr(q.flag, FLAG_NAN);
+    }
+
+    const long niter = (long)q.nbatch * q.blen * q.nspac;
+    const unsigned long long gens = q.ens_offset + (unsigned long long)e;
+    // Philox draws of iterations it0 .. it0+63, lane t <-> iteration it0+t (same counters as temper_kernel)
+    auto refill = [&](long it0) {
+        const unsigned long long g2 = q.iter_offset + (unsigned long long)it0 + (unsigned long long)lane;
+        double a, b;
+        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 0u, a, b);
+        Ubuf[lane * 4 + 0] = a; Ubuf[lane * 4 + 1] = b;
+        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 1u, a, b);
+        Ubuf[lane * 4 + 2] = a; Ubuf[lane * 4 + 3] = b;
+#pragma unroll
+        for (int j2 = 0; 2 * j2 < P; j2++) {
+            philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, g2, (uint32_t)(2 + j2), a, b);
+            Zbuf[lane * PZ + 2 * j2] = a; Zbuf[lane * PZ + 2 * j2 + 1] = b;
+        }
+    };
+    double cu[4], cz[P], nu[4], nz[P];
+    auto fetch = [&](long it, double *u, double *z) {
+        const double *up = inj ? q.unif + ((size_t)e * niter + it) * 4 : Ubuf + (it & 63) * 4;
+        const double *zp = inj ? q.norm + ((size_t)e * niter + it) * P : Zbuf + (it & 63) * PZ;
+#pragma unroll
+        for (int j = 0; j < 4; j++) u[j] = up[j];
+#pragma unroll
+        for (int j = 0; j < P; j++) z[j] = zp[j];
+    };
+    if (!inj) { refill(0); __syncthreads(); }
+    fetch(0, cu, cz);
+#pragma unroll
+    for (int j = 0; j < 4; j++) nu[j] = cu[j];
+#pragma unroll
+    for (int j = 0; j < P; j++) nz[j] = cz[j];
+
+    long it = 0;
+    for (int kb = 0; kb < q.nbatch; kb++) {
+        for (int jb = 0; jb < q.blen; jb++) {
+            for (int is = 0; is < q.nspac; is++, it++) {
+                if (it + 1 < niter) {              // next iteration's draws are in flight during this one
+                    if (!inj && ((it + 1) & 63) == 0) { __syncthreads(); refill(it + 1); __syncthreads(); }
+                    fetch(it + 1, nu, nz);
+                }
+                const int within = __builtin_amdgcn_readfirstlane((int)(cu[0] < 0.5));      // temper.c:537-538
+                const int l = __builtin_amdgcn_readfirstlane(pick1(cu[1], k)) - 1;          // component i (0-based)
+                double lh, ly = 0.0, sco = 0.0, spr = 0.0, y[P], xi[P];
+                int m = 0, slot_ = 0;
+#pragma unroll
+                for (int j = 0; j < P; j++) xi[j] = lane_read(x[j], l);
+                const double Li = lane_read(L, l);
+                if (within) {
+                    // proposal (temper.c:1003-1024)
+                    if (sk == MCMCHIP_SCALE_FULL) {
+                        const double *scf = gscale + (slist ? (size_t)l * P * P : 0);
+#pragma unroll
+                        for (int j = 0; j < P; j++) {
+                            double yj = xi[j];
+#pragma unroll
+                            for (int i = 0; i < P; i++) yj = add_nofma(yj, mul_nofma(scf[j + P * i], cz[i]));
+                            y[j] = yj;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < P; j++) y[j] = add_nofma(xi[j], mul_nofma(lane_read(sc[j], l), cz[j]));
+                    }
+                    ly = WITCH ? witch_value<P>(lane_read(wb, l), lane_read(win, l), lane_read(wco, l), y)
+                               : lud_temper(KIND, P, gpar, k, l + 1, y);
+                    lh = ly - Li;
+                    if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
+                } else {
+                    const int nni = __builtin_amdgcn_readlane(nn, l);
+                    slot_ = __builtin_amdgcn_readfirstlane(pick1(cu[2], nni)) - 1;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)nbp, l);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nbp >> 32), l);
+                    const unsigned long long row = ((unsigned long long)hi << 32) | lo;
+                    m = (int)((row >> (8 * slot_)) & 0xffu);                                // component j (0-based)
+                    double xj[P];
+#pragma unroll
+                    for (int j = 0; j < P; j++) xj[j] = lane_read(x[j], m);
+                    const double Lj = lane_read(L, m);
+                    if (WITCH) {
+                        sco = witch_value<P>(lane_read(wb, m), lane_read(win, m), lane_read(wco, m), xi);  // (j, x_i)
+                        spr = witch_value<P>(lane_read(wb, l), lane_read(win, l), lane_read(wco, l), xj);  // (i, x_j)
+                    } else {
+                        // lanes 0..31 evaluate (j, x_i), lanes 32..63 evaluate (i, x_j)
+                        const bool lowh = lane < 32;
+                        double th[P];
+#pragma unroll
+                        for (int j = 0; j < P; j++) th[j] = lowh ? xi[j] : xj[j];
+                        const double v = lud_temper(KIND, P, gpar, k, (lowh ? m : l) + 1, th);
+                        sco = lane_read(v, 0);
+                        spr = lane_read(v, 32);
+                    }
+                    lh = spr + sco - Lj - Li;                                               // temper.c:742-744
+                    if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (lane == 0) atomicOr(q.flag, FLAG_NAN); }
+#pragma unroll
+                    for (int j = 0; j < P; j++) y[j] = xj[j];
+                }
+                if (isnan(lh) || (isinf(lh) && lh > 0)) { if (lane == 0) atomicOr(q.flag, FLAG_HASTINGS); lh = -INFINITY; }
+                bool accept = true;
+                if (lh < 0.0) accept = cu[3] < exp(lh);                                     // temper.c:582-587
+                if (within) {
+                    if (lane == l) {
+                        axd++;
+                        if (accept) {
+                            axn++;
+                            L = ly;
+#pragma unroll
+                            for (int j = 0; j < P; j++) x[j] = y[j];
+                        }
+                    }
+                } else {
+                    if (accept) {
+                        if (lane == l) {
+                            L = spr;
+#pragma unroll
+                            for (int j = 0; j < P; j++) x[j] = y[j];
+                        } else if (lane == m) {
+                            L = sco;
+#pragma unroll
+                            for (int j = 0; j < P; j++) x[j] = xi[j];
+                        }
+                    }
+                    if (lane == 0) {
+                        if (accept) atomicAdd(&ain[l * maxnn + slot_], 1u);
+                        atomicAdd(&aid[l * maxnn + slot_], 1u);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) cu[j] = nu[j];
+#pragma unroll
+                for (int j = 0; j < P; j++) cz[j] = nz[j];
+            }
+            // batch accumulation once per blen step (temper.c:851-867)
+            if (!corner) {
+#pragma unroll
+                for (int j = 0; j < P; j++) acc[j] += x[j];
+            } else {                               // tests/temp-par-witch.R:52-59
+                bool all = true;
+#pragma unroll
+                for (int j = 0; j < P; j++) all &= fabs(x[j]) - wb > 0;
+                acc[0] += all ? 1.0 : 0.0;
+            }
+        }
+        if (live) {
+            if (!corner) {
+#pragma unroll
+                for (int j = 0; j < P; j++)
+                    q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * (c + k * j)] = acc[j] / q.blen;   // temper.c:871-875
+            } else {
+                q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * c] = acc[0] / q.blen;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < P; j++) acc[j] = 0.0;
+    }
+    __syncthreads();
+    if (live) {
+        q.acceptx[(size_t)e * k + c] = (double)axn / (double)axd;        // 0/0 = NaN (temper.c:889-890)
+        int slot = 0;
+        for (int j = 0; j < k; j++) {
+            double v = NAN;                                              // NA for non-neighbours (temper.c:896-897)
+            if (q.neighbors[c + k * j]) {
+                v = (double)ain[c * maxnn + slot] / (double)aid[c * maxnn + slot];
+                slot++;
+            }
+            q.accepti[(size_t)e * k * k + c + k * j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < P; j++) q.final_[(size_t)e * k * P + c + k * j] = x[j];
+    }
+}
+
+template <int P, int KIND>
+static int launch_temper_reg(const TemperDev &q, int maxnn, hipStream_t s)
+{
+    const int k = q.k;
+    TemperRegLds lay;
+    int o = 0;
+    lay.ubuf = o; o += 64 * 4;
+    lay.zbuf = o; o += 64 * ((P + 1) & ~1);
+    lay.ain = o; o += (k * maxnn + 1) / 2;
+    lay.aid = o; o += (k * maxnn + 1) / 2;
+    const long slen1h = (q.scale_kind & 7) == MCMCHIP_SCALE_FULL ? P * P : 0;     // constant / diagonal scales live in registers
+    const long nscale = (q.scale_kind & MCMCHIP_SCALE_LIST) ? slen1h * k : slen1h;
+    lay.npar_lds = (KIND != MCMCHIP_T_WITCH && q.npar > 0 && q.npar <= 2048) ? (int)q.npar : 0;
+    lay.nscale_lds = (int)nscale;
+    lay.par = o; o += lay.npar_lds;
+    lay.scale = o; o += lay.nscale_lds;
+    lay.end = o;
+    hipLaunchKernelGGL((temper_reg_kernel<P, KIND>), dim3((unsigned)q.nens), dim3(64), (size_t)o * 8, s, q, lay, maxnn);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
 int launch_temper(const TemperDev &q, hipStream_t s)
 {
     if (q.p > TEMPER_MAXP) return set_error(MCMCHIP_EINVAL, "tempering path supports state dimension <= %d", TEMPER_MAXP);
@@ -356,6 +640,19 @@ int launch_temper(const TemperDev &q, hipStream_t s)
             if (c > m) m = c;
         }
         maxnn = m;
+    }
+    // register-resident kernel for the common parallel-tempering shape; everything else takes temper_kernel
+    const bool reg_ok = q.parallel && !q.debug && k <= 64 && p >= 1 && p <= 4 && maxnn <= 8 &&
+                        (q.kind == MCMCHIP_T_WITCH || q.kind == MCMCHIP_T_TEMPERED_NORMMIX);
+    if (q.path == MCMCHIP_PATH_REG && !reg_ok)
+        return set_error(MCMCHIP_EINVAL, "register tempering path needs parallel = 1, debug = 0, k <= 64, p <= 4, "
+                                         "at most 8 neighbours per component and a closed-form descriptor");
+    if (reg_ok && q.path != MCMCHIP_PATH_LDS) {
+#define REG_CASE(PP) \
+        case PP: return q.kind == MCMCHIP_T_WITCH ? launch_temper_reg<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
+                                                  : launch_temper_reg<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
+        switch (p) { REG_CASE(1) REG_CASE(2) REG_CASE(3) REG_CASE(4) }
+#undef REG_CASE
     }
     const int nstate = q.parallel ? k * p : p + 1;
     const int nout = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (q.parallel ? k : 2 * k) : (q.parallel ? k * p : p);

@@ -64,19 +64,26 @@ def c4():
         init = np.tile(x0, (E, k, 1))
         api.temper(tg, init, nb, 2, 5, 5, 0.3, parallel=True, seed=3)
         nbatch, blen, nspac = 100, 10, 20
-        t0 = time.perf_counter()
-        o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3, parallel=True, seed=3)
-        el = time.perf_counter() - t0
-        kn, kms, _ = api.last_kernel_time()
         niter = nbatch * blen * nspac
         ot = oracle.Target(K, p, par=par)
         t0 = time.perf_counter()
         oracle.temper(ot, init[:16], nb, 20, blen, nspac, 0.3, parallel=True, seed=3, nthreads=16)
         cel = time.perf_counter() - t0
-        out.append({"config": "C4 temper parallel %s k=64 p=%d, 1024 ensembles x %d iterations" % (name, p, niter),
-                    "ensemble_iter_per_s": E * niter / el, "kernel": kn, "kernel_ms": kms,
-                    "acceptx_mean": float(np.nanmean(o["acceptx"])), "accepti_mean": float(np.nanmean(o["accepti"])),
-                    "cpu_oracle_16thr_ensemble_iter_per_s": 16 * 20 * blen * nspac / cel})
+        prev = None
+        for path, pname in ((abi.PATH_LDS, "lds"), (abi.PATH_REG, "reg")):
+            t0 = time.perf_counter()
+            o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3, parallel=True, seed=3, _path=path)
+            el = time.perf_counter() - t0
+            kn, kms, _ = api.last_kernel_time()
+            same = None if prev is None else bool(all(np.array_equal(prev[n], o[n], equal_nan=True)
+                                                      for n in ("final", "batch", "acceptx", "accepti")))
+            prev = o
+            out.append({"config": "C4 temper parallel %s k=64 p=%d, 1024 ensembles x %d iterations, %s kernel"
+                                  % (name, p, niter, pname),
+                        "ensemble_iter_per_s": E * niter / el, "kernel": kn, "kernel_ms": kms,
+                        "kernel_ensemble_iter_per_s": E * niter / (kms * 1e-3), "same_bits_as_lds_kernel": same,
+                        "acceptx_mean": float(np.nanmean(o["acceptx"])), "accepti_mean": float(np.nanmean(o["accepti"])),
+                        "cpu_oracle_16thr_ensemble_iter_per_s": 16 * 20 * blen * nspac / cel})
     return out
 
 

@@ -375,6 +375,59 @@ def test_temper_philox_matches_oracle_restatement(api, oracle_mod):
     assert np.array_equal(both["batch"][:, :20], a["batch"])    # restart continues the stream
 
 
+@pytest.mark.parametrize("target,p", [("witch", 1), ("witch", 3), ("witch", 4), ("mixture", 2), ("mixture", 3)])
+@pytest.mark.parametrize("k,nbrs", [(64, 1), (5, 2), (37, 4)])
+@pytest.mark.parametrize("scale_kind", ["scalar", "list_scalar", "list_vector", "matrix", "list_matrix"])
+def test_temper_register_kernel_equals_lds_kernel(api, oracle_mod, target, p, k, nbrs, scale_kind):
+    """the lane-per-component kernel (MCMCHIP_PATH_REG) and the LDS kernel give the same bits, with injected streams
+    and with device Philox, identity and corner-indicator output; spot check against the oracle"""
+    rng = np.random.default_rng(k * 100 + p)
+    E, nbatch, blen, nspac = 9, 7, 6, 3
+    niter = nbatch * blen * nspac
+    if target == "witch":
+        par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / (8.0 * p))
+        K, x0 = abi.T_WITCH, np.zeros(p)
+    else:
+        betas = np.geomspace(1.0, 0.05, k)
+        par = np.concatenate([[float(k)], betas, abi.normmix_par([0.3, 0.7], [np.full(p, -3.0), np.full(p, 3.0)], 1.0)])
+        K, x0 = abi.T_TEMPERED_NORMMIX, np.full(p, 3.0)
+    i, j = np.indices((k, k))
+    nb = (np.abs(i - j) >= 1) & (np.abs(i - j) <= nbrs)
+    scale = {"scalar": 0.4, "list_scalar": [0.2 + 0.01 * c for c in range(k)],
+             "list_vector": [np.full(p, 0.2 + 0.01 * c) + 0.05 * np.arange(p) for c in range(k)],
+             "matrix": 0.3 * np.linalg.cholesky(np.eye(p) + 0.5),
+             "list_matrix": [(0.2 + 0.01 * c) * np.linalg.cholesky(np.eye(p) + 0.5) for c in range(k)]}[scale_kind]
+    init = np.tile(x0, (E, k, 1)) + 0.01 * rng.standard_normal((E, k, p))
+    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+    tg = api.Target(K, p, par=par)
+    outs = [None, "witch.corner"] if target == "witch" else [None]
+    for outfun in outs:
+        for kw in (dict(unif=unif, norm=norm), dict(seed=77, ens_offset=3)):
+            a = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=abi.PATH_LDS, **kw)
+            b = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=abi.PATH_REG, **kw)
+            for name in ("final", "batch", "acceptx", "accepti"):
+                assert np.array_equal(a[name], b[name], equal_nan=True), (name, outfun, list(kw))
+    ref = oracle_mod.temper(oracle_mod.Target(K, p, par=par), init, nb, nbatch, blen, nspac, scale, parallel=True,
+                            unif=unif, norm=norm)
+    o = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, unif=unif, norm=norm, _path=abi.PATH_REG)
+    assert np.array_equal(o["final"], ref["final"])
+    assert np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True)
+    assert np.array_equal(o["accepti"], ref["accepti"], equal_nan=True)
+    assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
+
+
+def test_temper_register_kernel_refuses_other_shapes(api):
+    k, p = 4, 3
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    i, j = np.indices((k, k))
+    nb = np.abs(i - j) == 1
+    tg = api.Target(abi.T_WITCH, p, par=par)
+    with pytest.raises(Exception, match="register tempering path"):
+        api.temper(tg, np.array([1.0, 0, 0, 0]), nb, 5, 1, 1, 0.3, parallel=False, seed=1, _path=abi.PATH_REG)
+    with pytest.raises(Exception, match="register tempering path"):
+        api.temper(tg, np.zeros((k, p)), nb, 5, 1, 1, 0.3, parallel=True, debug=True, seed=1, _path=abi.PATH_REG)
+
+
 # ----------------------------------------------------------------------------- initseq / olbm
 def test_diag_golden_vectors(api):
     g = np.load(os.path.join(GOLDEN, "diag.npz"))
