@@ -199,7 +199,7 @@ enum {
 /* temper kernels (args.path; AUTO = 0 picks): LDS = one wavefront per ensemble with the state in LDS (any shape,
  * serial tempering, debug trace); REG = lane-per-component registers (parallel, k <= 64, p <= 4, closed-form
  * descriptors, no trace).  Same results bit for bit. */
-enum { MCMCHIP_PATH_LDS = 1, MCMCHIP_PATH_REG = 2 };
+enum { MCMCHIP_PATH_LDS = 1, MCMCHIP_PATH_REG = 2, MCMCHIP_PATH_RUN = 3 };
 
 typedef struct mcmchip_temper_args {
     int64_t nens;

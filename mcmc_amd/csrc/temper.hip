@@ -620,6 +620,295 @@ static int launch_temper_reg(const TemperDev &q, int maxnn, hipStream_t s)
     return MCMCHIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Run-parallel variant.  Elementary updates that touch DISJOINT components commute: a within-component
+// step reads and writes one row of the state, a swap two rows, and each iteration owns its own random
+// numbers (fixed Philox counters / injected slots).  So a maximal RUN of consecutive iterations whose
+// component sets are pairwise disjoint can be executed in one pass, every touched component updated by
+// its own lane at the same time; the result is the sequential one, bit for bit.  Per window of 64
+// iterations: lane t draws iteration t's numbers and decodes (within | swap, i, j, slot); a scalar scan
+// over the 64 component masks cuts the window into runs (also at batch ends); per run the iterations
+// scatter their index to their components' lanes through LDS, each such lane gathers its z / u, fetches the
+// partner row by ds_bpermute for a swap, and ONE log-density evaluation, one exp and one predicated
+// commit serve the whole run.  With k = 64 a run holds ~6 iterations.  Batch sums are added per
+// accumulation point in time order with the value each lane held at that point (before or after its
+// update), so they too equal the sequential sums exactly.
+struct TemperRunLds {
+    int zbuf, u3buf, desc, own, nnT, nbT, ain, aid, par, scale, end;   // offsets in 8-byte words
+    int npar_lds, nscale_lds;
+};
+
+template <int P, int KIND>
+__global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLds lay, int maxnn)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long e = blockIdx.x;
+    const int k = q.k;
+    constexpr int PZ = (P + 1) & ~1;
+    constexpr bool WITCH = KIND == MCMCHIP_T_WITCH;
+    const bool corner = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER;
+    const int nout = corner ? k : k * P;
+    double *Zbuf = lds + lay.zbuf, *U3 = lds + lay.u3buf;
+    unsigned *desc = (unsigned *)(lds + lay.desc);
+    int *own = (int *)(lds + lay.own);
+    int *nnT = (int *)(lds + lay.nnT), *nbT = (int *)(lds + lay.nbT);
+    unsigned *ain = (unsigned *)(lds + lay.ain), *aid = (unsigned *)(lds + lay.aid);
+    const double *gpar = q.par, *gscale = q.scale;
+    if (lay.npar_lds > 0) {
+        double *lp = lds + lay.par;
+        for (int i = lane; i < lay.npar_lds; i += 64) lp[i] = q.par[i];
+        gpar = lp;
+    }
+    if (lay.nscale_lds > 0) {
+        double *ls = lds + lay.scale;
+        for (int i = lane; i < lay.nscale_lds; i += 64) ls[i] = q.scale[i];
+        gscale = ls;
+    }
+    for (int i = lane; i < k * maxnn; i += 64) ain[i] = aid[i] = 0;
+    const bool live = lane < k;
+    const int c = live ? lane : 0;                 // idle lanes shadow component 0 and never commit
+    const int sk = q.scale_kind & 7;
+    const bool slist = (q.scale_kind & MCMCHIP_SCALE_LIST) != 0;
+    const bool inj = q.rng_mode == MCMCHIP_RNG_INJECTED;
+
+    double x[P], acc[P], sc[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        x[j] = q.initial[(size_t)e * k * P + c + k * j];
+        acc[j] = 0.0;
+        sc[j] = sk == MCMCHIP_SCALE_CONSTANT ? q.scale[slist ? c : 0]
+              : sk == MCMCHIP_SCALE_DIAGONAL ? q.scale[(slist ? c * P : 0) + j] : 0.0;
+    }
+    const double *scf = gscale + (slist ? (size_t)c * P * P : 0);      // full-matrix scale of this lane's component
+    if (live) {
+        int n = 0;
+        for (int j = 0; j < k; j++)
+            if (q.neighbors[c + k * j]) nbT[c * maxnn + n++] = j;     // ascending (temper.c:504-510)
+        nnT[c] = n;
+    }
+    unsigned axn = 0, axd = 0;
+    double wb = 0.0, win = 0.0, wco = 0.0;
+    if (WITCH) { wb = q.par[c]; win = q.par[k + c]; wco = q.par[2 * k + c]; }
+    __syncthreads();
+    auto LUD_OWN = [&](const double *th) -> double {                  // log density of (component c, th)
+        if (WITCH) return witch_value<P>(wb, win, wco, th);
+        return lud_temper(KIND, P, gpar, k, c + 1, th);
+    };
+    double L = LUD_OWN(x);                                            // temper.c:98-119
+    if (live) {
+        if (L == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+        else if (L == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+        else if (isnan(L)) atomicOr(q.flag, FLAG_NAN);
+    }
+
+    const long niter = (long)q.nbatch * q.blen * q.nspac;
+    const unsigned long long gens = q.ens_offset + (unsigned long long)e;
+    const unsigned long long per = (unsigned long long)q.blen * (unsigned long long)q.nspac;   // iterations per batch
+    const unsigned nspac = (unsigned)q.nspac;
+    int kb = 0;
+
+    for (long it0 = 0; it0 < niter; it0 += 64) {
+        const int nvalid = (int)(niter - it0 < 64 ? niter - it0 : 64);
+        const bool valid = lane < nvalid;
+        // ---- lane t: the draws and the decoded move of iteration it0 + t
+        double u0 = 1.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, zt[PZ];
+#pragma unroll
+        for (int j = 0; j < PZ; j++) zt[j] = 0.0;
+        if (valid) {
+            if (inj) {
+                const double *up = q.unif + ((size_t)e * niter + it0 + lane) * 4;
+                u0 = up[0]; u1 = up[1]; u2 = up[2]; u3 = up[3];
+                const double *zp = q.norm + ((size_t)e * niter + it0 + lane) * P;
+#pragma unroll
+                for (int j = 0; j < P; j++) zt[j] = zp[j];
+            } else {
+                const unsigned long long g2 = q.iter_offset + (unsigned long long)it0 + (unsigned long long)lane;
+                philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 0u, u0, u1);
+                philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 1u, u2, u3);
+#pragma unroll
+                for (int j2 = 0; 2 * j2 < P; j2++)
+                    philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, g2, (uint32_t)(2 + j2), zt[2 * j2], zt[2 * j2 + 1]);
+            }
+        }
+        const bool t_within = u0 < 0.5;                                // temper.c:537-538
+        const int t_l = valid ? pick1(u1, k) - 1 : 0;
+        int t_m = t_l, t_slot = 0;
+        if (valid && !t_within) {
+            t_slot = pick1(u2, nnT[t_l]) - 1;
+            t_m = nbT[t_l * maxnn + t_slot];
+        }
+        const unsigned long long bits = valid ? (1ull << t_l) | (1ull << t_m) : 0ull;
+        // accumulation points (every nspac iterations, temper.c:851-867) and batch ends, as lane masks
+        const unsigned long long gi = (unsigned long long)it0 + (unsigned long long)lane + 1ull;
+        const unsigned long long Am = __ballot(valid && (nspac == 1u || gi % nspac == 0ull));
+        const unsigned long long Bm = __ballot(valid && gi % per == 0ull);
+        __syncthreads();                                               // previous window's readers are done
+#pragma unroll
+        for (int j = 0; j < PZ; j++) Zbuf[lane * PZ + j] = zt[j];
+        U3[lane] = u3;
+        desc[lane] = (unsigned)t_l | ((unsigned)t_m << 8) | ((unsigned)t_slot << 16) | ((unsigned)t_within << 24);
+        __syncthreads();
+
+        // ---- cut the window into runs of pairwise disjoint iterations and execute each run
+        unsigned long long cur = 0;
+        int rs = 0;
+        for (int t = 0; t <= nvalid; t++) {
+            unsigned long long b = 0;
+            if (t < nvalid) {
+                const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, t);
+                const unsigned bhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), t);
+                b = ((unsigned long long)bhi << 32) | blo;
+            }
+            const bool bend_prev = t > 0 && ((Bm >> (t - 1)) & 1ull);
+            if (t > rs && (t == nvalid || bend_prev || (b & cur))) {
+                // ===== run [rs, t)
+                own[lane] = -1;
+                __syncthreads();
+                if (lane >= rs && lane < t) {
+                    own[t_l] = lane * 4 + (t_within ? 0 : 1);
+                    if (!t_within) own[t_m] = lane * 4 + 2;
+                }
+                __syncthreads();
+                const int o = own[lane];
+                const bool active = o >= 0;
+                const int ti = active ? (o >> 2) : 0;                 // this lane's iteration within the window
+                const int role = o & 3;                                // 0 within, 1 swap (component i), 2 swap (component j)
+                const unsigned d = desc[ti];
+                const int d_l = d & 0xff, d_m = (d >> 8) & 0xff, d_slot = (d >> 16) & 0xff;
+                const bool sw = active && role != 0;
+                const int partner = sw ? (role == 1 ? d_m : d_l) : lane;
+                const double uh = U3[ti];
+                double xq[P], th[P], xold[P];
+#pragma unroll
+                for (int j = 0; j < P; j++) { xq[j] = __shfl(x[j], partner); xold[j] = x[j]; }
+                const double Lq = __shfl(L, partner);
+                // within: proposal (temper.c:1003-1024); swap: the partner's row
+                if (sk == MCMCHIP_SCALE_FULL) {
+#pragma unroll
+                    for (int j = 0; j < P; j++) {
+                        double yj = x[j];
+#pragma unroll
+                        for (int i = 0; i < P; i++) yj = add_nofma(yj, mul_nofma(scf[j + P * i], Zbuf[ti * PZ + i]));
+                        th[j] = sw ? xq[j] : yj;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < P; j++) {
+                        const double yj = add_nofma(x[j], mul_nofma(sc[j], Zbuf[ti * PZ + j]));
+                        th[j] = sw ? xq[j] : yj;
+                    }
+                }
+                const double v = LUD_OWN(th);     // within: lud(i, y); swap: lud(own component, partner's row)
+                const double vq = __shfl(v, partner);
+                double lh;
+                if (sw) {
+                    const double spr = role == 1 ? v : vq;            // (i, x_j)
+                    const double sco = role == 1 ? vq : v;            // (j, x_i)
+                    const double Li = role == 1 ? L : Lq, Lj = role == 1 ? Lq : L;
+                    lh = spr + sco - Lj - Li;                          // temper.c:742-744
+                    if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (role == 1) atomicOr(q.flag, FLAG_NAN); }
+                } else {
+                    lh = v - L;
+                    if (active && (v == INFINITY || isnan(v))) atomicOr(q.flag, isnan(v) ? FLAG_NAN : FLAG_POSINF);
+                }
+                if (isnan(lh) || (isinf(lh) && lh > 0)) { if (active && role != 2) atomicOr(q.flag, FLAG_HASTINGS); lh = -INFINITY; }
+                bool accept = true;
+                if (lh < 0.0) accept = uh < exp(lh);                   // temper.c:582-587
+                if (active) {
+                    if (accept) {
+                        L = v;
+#pragma unroll
+                        for (int j = 0; j < P; j++) x[j] = th[j];
+                    }
+                    if (role == 0) { axd++; if (accept) axn++; }
+                    else if (role == 1) {
+                        if (accept) atomicAdd(&ain[lane * maxnn + d_slot], 1u);
+                        atomicAdd(&aid[lane * maxnn + d_slot], 1u);
+                    }
+                }
+                // batch sums: the accumulation points of the run in time order, each with the value this lane
+                // held at that point (its update happens at iteration ti)
+                unsigned long long am = Am & ((t >= 64 ? ~0ull : ((1ull << t) - 1ull)) & ~((1ull << rs) - 1ull));
+                const int tau = active ? ti : -1;
+                while (am) {
+                    const int tp = __builtin_ctzll(am);
+                    am &= am - 1ull;
+                    const bool pre = tp < tau;
+                    if (!corner) {
+#pragma unroll
+                        for (int j = 0; j < P; j++) acc[j] += pre ? xold[j] : x[j];
+                    } else {                                           // tests/temp-par-witch.R:52-59
+                        bool all = true;
+#pragma unroll
+                        for (int j = 0; j < P; j++) all &= fabs(pre ? xold[j] : x[j]) - wb > 0;
+                        acc[0] += all ? 1.0 : 0.0;
+                    }
+                }
+                if (bend_prev) {                                       // the run ended a batch (temper.c:871-875)
+                    if (live) {
+                        if (!corner) {
+#pragma unroll
+                            for (int j = 0; j < P; j++)
+                                q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * (c + k * j)] = acc[j] / q.blen;
+                        } else {
+                            q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * c] = acc[0] / q.blen;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < P; j++) acc[j] = 0.0;
+                    kb++;
+                }
+                rs = t;
+                cur = 0;
+            }
+            cur |= b;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        q.acceptx[(size_t)e * k + c] = (double)axn / (double)axd;        // 0/0 = NaN (temper.c:889-890)
+        int slot = 0;
+        for (int j = 0; j < k; j++) {
+            double v = NAN;                                              // NA for non-neighbours (temper.c:896-897)
+            if (q.neighbors[c + k * j]) {
+                v = (double)ain[c * maxnn + slot] / (double)aid[c * maxnn + slot];
+                slot++;
+            }
+            q.accepti[(size_t)e * k * k + c + k * j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < P; j++) q.final_[(size_t)e * k * P + c + k * j] = x[j];
+    }
+}
+
+template <int P, int KIND>
+static int launch_temper_run(const TemperDev &q, int maxnn, hipStream_t s)
+{
+    const int k = q.k;
+    TemperRunLds lay;
+    int o = 0;
+    lay.zbuf = o; o += 64 * ((P + 1) & ~1);
+    lay.u3buf = o; o += 64;
+    lay.desc = o; o += 32;
+    lay.own = o; o += 32;
+    lay.nnT = o; o += (k + 1) / 2;
+    lay.nbT = o; o += (k * maxnn + 1) / 2;
+    lay.ain = o; o += (k * maxnn + 1) / 2;
+    lay.aid = o; o += (k * maxnn + 1) / 2;
+    const long slen1h = (q.scale_kind & 7) == MCMCHIP_SCALE_FULL ? P * P : 0;
+    const long nscale = (q.scale_kind & MCMCHIP_SCALE_LIST) ? slen1h * k : slen1h;
+    lay.npar_lds = (KIND != MCMCHIP_T_WITCH && q.npar > 0 && q.npar <= 2048) ? (int)q.npar : 0;
+    lay.nscale_lds = (int)nscale;
+    lay.par = o; o += lay.npar_lds;
+    lay.scale = o; o += lay.nscale_lds;
+    lay.end = o;
+    hipLaunchKernelGGL((temper_run_kernel<P, KIND>), dim3((unsigned)q.nens), dim3(64), (size_t)o * 8, s, q, lay, maxnn);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
 int launch_temper(const TemperDev &q, hipStream_t s)
 {
     if (q.p > TEMPER_MAXP) return set_error(MCMCHIP_EINVAL, "tempering path supports state dimension <= %d", TEMPER_MAXP);
@@ -647,10 +936,17 @@ int launch_temper(const TemperDev &q, hipStream_t s)
     if (q.path == MCMCHIP_PATH_REG && !reg_ok)
         return set_error(MCMCHIP_EINVAL, "register tempering path needs parallel = 1, debug = 0, k <= 64, p <= 4, "
                                          "at most 8 neighbours per component and a closed-form descriptor");
+    if (q.path == MCMCHIP_PATH_RUN && !reg_ok)
+        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path has the requirements of the register tempering path");
     if (reg_ok && q.path != MCMCHIP_PATH_LDS) {
+        // runs of disjoint iterations only pay off when there are enough components to keep them long
+        const bool runs = q.path == MCMCHIP_PATH_RUN || (q.path == MCMCHIP_PATH_AUTO && k >= 16);
 #define REG_CASE(PP) \
-        case PP: return q.kind == MCMCHIP_T_WITCH ? launch_temper_reg<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
-                                                  : launch_temper_reg<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
+        case PP: \
+            if (runs) return q.kind == MCMCHIP_T_WITCH ? launch_temper_run<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
+                                                       : launch_temper_run<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s); \
+            return q.kind == MCMCHIP_T_WITCH ? launch_temper_reg<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
+                                             : launch_temper_reg<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
         switch (p) { REG_CASE(1) REG_CASE(2) REG_CASE(3) REG_CASE(4) }
 #undef REG_CASE
     }

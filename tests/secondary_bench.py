@@ -70,7 +70,7 @@ def c4():
         oracle.temper(ot, init[:16], nb, 20, blen, nspac, 0.3, parallel=True, seed=3, nthreads=16)
         cel = time.perf_counter() - t0
         prev = None
-        for path, pname in ((abi.PATH_LDS, "lds"), (abi.PATH_REG, "reg")):
+        for path, pname in ((abi.PATH_LDS, "lds"), (abi.PATH_REG, "reg"), (abi.PATH_RUN, "run")):
             t0 = time.perf_counter()
             o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3, parallel=True, seed=3, _path=path)
             el = time.perf_counter() - t0

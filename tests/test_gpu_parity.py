@@ -379,11 +379,11 @@ def test_temper_philox_matches_oracle_restatement(api, oracle_mod):
 @pytest.mark.parametrize("k,nbrs", [(64, 1), (5, 2), (37, 4)])
 @pytest.mark.parametrize("scale_kind", ["scalar", "list_scalar", "list_vector", "matrix", "list_matrix"])
 def test_temper_register_kernel_equals_lds_kernel(api, oracle_mod, target, p, k, nbrs, scale_kind):
-    """the lane-per-component kernel (MCMCHIP_PATH_REG) and the LDS kernel give the same bits, with injected streams
-    and with device Philox, identity and corner-indicator output; spot check against the oracle"""
+    """the lane-per-component kernel (MCMCHIP_PATH_REG), the run-parallel kernel (MCMCHIP_PATH_RUN) and the LDS
+    kernel give the same bits, with injected streams and with device Philox, identity and corner-indicator output,
+    thinned and unthinned batches; spot check against the oracle"""
     rng = np.random.default_rng(k * 100 + p)
-    E, nbatch, blen, nspac = 9, 7, 6, 3
-    niter = nbatch * blen * nspac
+    E = 9
     if target == "witch":
         par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / (8.0 * p))
         K, x0 = abi.T_WITCH, np.zeros(p)
@@ -398,22 +398,26 @@ def test_temper_register_kernel_equals_lds_kernel(api, oracle_mod, target, p, k,
              "matrix": 0.3 * np.linalg.cholesky(np.eye(p) + 0.5),
              "list_matrix": [(0.2 + 0.01 * c) * np.linalg.cholesky(np.eye(p) + 0.5) for c in range(k)]}[scale_kind]
     init = np.tile(x0, (E, k, 1)) + 0.01 * rng.standard_normal((E, k, p))
-    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
     tg = api.Target(K, p, par=par)
     outs = [None, "witch.corner"] if target == "witch" else [None]
-    for outfun in outs:
-        for kw in (dict(unif=unif, norm=norm), dict(seed=77, ens_offset=3)):
-            a = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=abi.PATH_LDS, **kw)
-            b = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=abi.PATH_REG, **kw)
-            for name in ("final", "batch", "acceptx", "accepti"):
-                assert np.array_equal(a[name], b[name], equal_nan=True), (name, outfun, list(kw))
+    for nbatch, blen, nspac in ((7, 6, 3), (150, 1, 1), (3, 43, 1), (2, 1, 70)):
+        niter = nbatch * blen * nspac
+        unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+        for outfun in outs:
+            for kw in (dict(unif=unif, norm=norm), dict(seed=77, ens_offset=3)):
+                a = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=abi.PATH_LDS, **kw)
+                for path in (abi.PATH_REG, abi.PATH_RUN):
+                    b = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=path, **kw)
+                    for name in ("final", "batch", "acceptx", "accepti"):
+                        assert np.array_equal(a[name], b[name], equal_nan=True), (name, outfun, list(kw), path, nbatch)
     ref = oracle_mod.temper(oracle_mod.Target(K, p, par=par), init, nb, nbatch, blen, nspac, scale, parallel=True,
                             unif=unif, norm=norm)
-    o = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, unif=unif, norm=norm, _path=abi.PATH_REG)
-    assert np.array_equal(o["final"], ref["final"])
-    assert np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True)
-    assert np.array_equal(o["accepti"], ref["accepti"], equal_nan=True)
-    assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
+    for path in (abi.PATH_REG, abi.PATH_RUN):
+        o = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, unif=unif, norm=norm, _path=path)
+        assert np.array_equal(o["final"], ref["final"])
+        assert np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True)
+        assert np.array_equal(o["accepti"], ref["accepti"], equal_nan=True)
+        assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
 
 
 def test_temper_register_kernel_refuses_other_shapes(api):
