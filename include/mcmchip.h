@@ -197,9 +197,9 @@ enum {
     MCMCHIP_TOUT_WITCH_CORNER = 1
 };
 /* temper kernels (args.path; AUTO = 0 picks): LDS = one wavefront per ensemble with the state in LDS (any shape,
- * serial tempering, debug trace); REG = lane-per-component registers (parallel, k <= 64, p <= 4, closed-form
- * descriptors, no trace).  Same results bit for bit. */
-enum { MCMCHIP_PATH_LDS = 1, MCMCHIP_PATH_REG = 2, MCMCHIP_PATH_RUN = 3 };
+ * serial tempering, debug trace); RUN = lane-per-component registers, runs of iterations on disjoint components
+ * executed together (parallel, k <= 64, p <= 4, closed-form descriptors, no trace).  Same results bit for bit. */
+enum { MCMCHIP_PATH_LDS = 1, MCMCHIP_PATH_RUN = 2 };
 
 typedef struct mcmchip_temper_args {
     int64_t nens;
@@ -221,7 +221,7 @@ typedef struct mcmchip_temper_args {
     int32_t device_ptrs;
     int32_t debug;                   /* fill the debug trace (temper.c:282-464, vignettes/debug.Rnw:64-243) */
     int32_t out_kind;                /* output functional (temper.c:977-988 evaluates an R closure): MCMCHIP_TOUT_* */
-    int32_t path;                    /* MCMCHIP_PATH_AUTO, or force one kernel: MCMCHIP_PATH_LDS | MCMCHIP_PATH_REG */
+    int32_t path;                    /* MCMCHIP_PATH_AUTO, or force one kernel: MCMCHIP_PATH_LDS | MCMCHIP_PATH_RUN */
 } mcmchip_temper_args;
 
 typedef struct mcmchip_temper_out {

@@ -454,8 +454,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
         return set_error(MCMCHIP_EINVAL, "argument \"outfun\" must be function or NULL");     // temper.c:68-69
     if (a->out_kind == MCMCHIP_TOUT_WITCH_CORNER && t->kind != MCMCHIP_T_WITCH)
         return set_error(MCMCHIP_EINVAL, "the corner-indicator output functional belongs to the witch's hat descriptor");
-    if (a->path != MCMCHIP_PATH_AUTO && a->path != MCMCHIP_PATH_LDS && a->path != MCMCHIP_PATH_REG &&
-        a->path != MCMCHIP_PATH_RUN)
+    if (a->path != MCMCHIP_PATH_AUTO && a->path != MCMCHIP_PATH_LDS && a->path != MCMCHIP_PATH_RUN)
         return set_error(MCMCHIP_EINVAL, "unknown temper path %d", a->path);
     const int nout = a->out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (a->parallel ? k : 2 * k) : (a->parallel ? k * p : p);
     InBuf init, scale, nbrs, unif, norm;

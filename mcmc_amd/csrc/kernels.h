@@ -64,7 +64,7 @@ struct TemperDev {
     double *batch, *ibatch, *acceptx, *accepti, *final_;
     int debug;
     int out_kind;             // MCMCHIP_TOUT_*
-    int path;                 // MCMCHIP_PATH_AUTO | _LDS | _REG
+    int path;                 // MCMCHIP_PATH_AUTO | _LDS | _RUN
     int *dbg_which, *dbg_acceptd;
     double *dbg_unif_which, *dbg_state, *dbg_lh, *dbg_uh, *dbg_proposal, *dbg_norm, *dbg_unif_choose, *dbg_coproposal;
     int *flag;

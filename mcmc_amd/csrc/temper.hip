@@ -338,28 +338,21 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
 
 
 // ---------------------------------------------------------------------------------------------
-// Register-resident variant for the common shape of parallel tempering: k <= 64 components of dimension
-// P <= 4 with closed-form densities (C4: 64 temperatures, witch's hat p = 3 / tempered mixture p = 2).
-// Lane c of the ensemble's wavefront OWNS component c: its state x[P], its cached log density
-// (temper.c:123-124), its batch accumulator and its within-acceptance counters are registers of that
-// lane.  The elementary update is wave-uniform: the chosen component's row is fetched with v_readlane
-// (no LDS round trip), the proposal / density / Hastings ratio are evaluated redundantly by all lanes,
-// and the accepted row is written back with a lane-predicated move; a swap (temper.c:679-781) is two
-// readlanes and two predicated moves, its two densities evaluated side by side on the two half-waves.
-// Random numbers of iteration it+1 are fetched while iteration it runs.  Same draw order, same Philox
-// counters and the same arithmetic as temper_kernel: results are bitwise the same (tested).
-struct TemperRegLds {
-    int ubuf, zbuf, ain, aid, par, scale, end;   // offsets in 8-byte words
-    int npar_lds, nscale_lds;
-};
-
-__device__ __forceinline__ double lane_read(double v, int l)     // l wave-uniform
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
+// Run-parallel variant for the common shape of parallel tempering: k <= 64 components of dimension P <= 4 with
+// closed-form densities (C4: 64 temperatures, witch's hat p = 3 / tempered mixture p = 2).  Lane c of the ensemble's
+// wavefront OWNS component c: its state x[P], its cached log density (temper.c:123-124), its batch accumulator
+// and its within-acceptance counters are registers of that lane.  Elementary updates that touch DISJOINT components commute: a within-component
+// step reads and writes one row of the state, a swap two rows, and each iteration owns its own random
+// numbers (fixed Philox counters / injected slots).  So a maximal RUN of consecutive iterations whose
+// component sets are pairwise disjoint can be executed in one pass, every touched component updated by
+// its own lane at the same time; the result is the sequential one, bit for bit.  Per window of 64
+// iterations: lane t draws iteration t's numbers and decodes (within | swap, i, j, slot); a scalar scan
+// over the 64 component masks cuts the window into runs (also at batch ends); per run the iterations
+// scatter their index to their components' lanes through LDS, each such lane gathers its z / u, fetches the
+// partner row by ds_bpermute for a swap, and ONE log-density evaluation, one exp and one predicated
+// commit serve the whole run.  With k = 64 a run holds ~6 iterations.  Batch sums are added per
+// accumulation point in time order with the value each lane held at that point (before or after its
+// update), so they too equal the sequential sums exactly.
 template <int P> __device__ __forceinline__ double witch_value(double bnd, double inside, double cornerv, const double *th)
 {
     bool out = false, all = true;                  // same tests as lud_temper's WITCH case
@@ -372,268 +365,6 @@ template <int P> __device__ __forceinline__ double witch_value(double bnd, doubl
     return out ? -INFINITY : (all ? cornerv : inside);
 }
 
-template <int P, int KIND>
-__global__ __launch_bounds__(64) void temper_reg_kernel(TemperDev q, TemperRegLds lay, int maxnn)
-{
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const long e = blockIdx.x;
-    const int k = q.k;
-    constexpr int PZ = (P + 1) & ~1;
-    constexpr bool WITCH = KIND == MCMCHIP_T_WITCH;
-    const bool corner = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER;
-    const int nout = corner ? k : k * P;
-    double *Ubuf = lds + lay.ubuf, *Zbuf = lds + lay.zbuf;
-    unsigned *ain = (unsigned *)(lds + lay.ain), *aid = (unsigned *)(lds + lay.aid);
-    const double *gpar = q.par, *gscale = q.scale;
-    if (lay.npar_lds > 0) {
-        double *lp = lds + lay.par;
-        for (int i = lane; i < lay.npar_lds; i += 64) lp[i] = q.par[i];
-        gpar = lp;
-    }
-    if (lay.nscale_lds > 0) {
-        double *ls = lds + lay.scale;
-        for (int i = lane; i < lay.nscale_lds; i += 64) ls[i] = q.scale[i];
-        gscale = ls;
-    }
-    for (int i = lane; i < k * maxnn; i += 64) ain[i] = aid[i] = 0;
-    const bool live = lane < k;
-    const int c = live ? lane : 0;                 // idle lanes shadow component 0 and never write
-    const int sk = q.scale_kind & 7;
-    const bool slist = (q.scale_kind & MCMCHIP_SCALE_LIST) != 0;
-    const bool inj = q.rng_mode == MCMCHIP_RNG_INJECTED;
-
-    double x[P], acc[P], sc[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-        x[j] = q.initial[(size_t)e * k * P + c + k * j];
-        acc[j] = 0.0;
-        // constant scale = diagonal scale with equal entries (same multiply, same add)
-        sc[j] = sk == MCMCHIP_SCALE_CONSTANT ? q.scale[slist ? c : 0]
-              : sk == MCMCHIP_SCALE_DIAGONAL ? q.scale[(slist ? c * P : 0) + j] : 0.0;
-    }
-    int nn = 0;
-    unsigned long long nbp = 0;                    // neighbours of component c, ascending (temper.c:504-510), 8 bits each
-    for (int j = 0; j < k; j++)
-        if (q.neighbors[c + k * j]) { nbp |= (unsigned long long)j << (8 * nn); nn++; }
-    unsigned axn = 0, axd = 0;
-    double wb = 0.0, win = 0.0, wco = 0.0;
-    if (WITCH) { wb = q.par[c]; win = q.par[k + c]; wco = q.par[2 * k + c]; }
-    __syncthreads();
-
-    double L = WITCH ? witch_value<P>(wb, win, wco, x) : lud_temper(KIND, P, gpar, k, c + 1, x);   // temper.c:98-119
-    if (live) {
-        if (L == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
-        else if (L == INFINITY) atomicOr(q.flag, FLAG_POSINF);
-        else if (isnan(L)) atomicOr(q.flag, FLAG_NAN);
-    }
-
-    const long niter = (long)q.nbatch * q.blen * q.nspac;
-    const unsigned long long gens = q.ens_offset + (unsigned long long)e;
-    // Philox draws of iterations it0 .. it0+63, lane t <-> iteration it0+t (same counters as temper_kernel)
-    auto refill = [&](long it0) {
-        const unsigned long long g2 = q.iter_offset + (unsigned long long)it0 + (unsigned long long)lane;
-        double a, b;
-        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 0u, a, b);
-        Ubuf[lane * 4 + 0] = a; Ubuf[lane * 4 + 1] = b;
-        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 1u, a, b);
-        Ubuf[lane * 4 + 2] = a; Ubuf[lane * 4 + 3] = b;
-#pragma unroll
-        for (int j2 = 0; 2 * j2 < P; j2++) {
-            philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, g2, (uint32_t)(2 + j2), a, b);
-            Zbuf[lane * PZ + 2 * j2] = a; Zbuf[lane * PZ + 2 * j2 + 1] = b;
-        }
-    };
-    double cu[4], cz[P], nu[4], nz[P];
-    auto fetch = [&](long it, double *u, double *z) {
-        const double *up = inj ? q.unif + ((size_t)e * niter + it) * 4 : Ubuf + (it & 63) * 4;
-        const double *zp = inj ? q.norm + ((size_t)e * niter + it) * P : Zbuf + (it & 63) * PZ;
-#pragma unroll
-        for (int j = 0; j < 4; j++) u[j] = up[j];
-#pragma unroll
-        for (int j = 0; j < P; j++) z[j] = zp[j];
-    };
-    if (!inj) { refill(0); __syncthreads(); }
-    fetch(0, cu, cz);
-#pragma unroll
-    for (int j = 0; j < 4; j++) nu[j] = cu[j];
-#pragma unroll
-    for (int j = 0; j < P; j++) nz[j] = cz[j];
-
-    long it = 0;
-    for (int kb = 0; kb < q.nbatch; kb++) {
-        for (int jb = 0; jb < q.blen; jb++) {
-            for (int is = 0; is < q.nspac; is++, it++) {
-                if (it + 1 < niter) {              // next iteration's draws are in flight during this one
-                    if (!inj && ((it + 1) & 63) == 0) { __syncthreads(); refill(it + 1); __syncthreads(); }
-                    fetch(it + 1, nu, nz);
-                }
-                const int within = __builtin_amdgcn_readfirstlane((int)(cu[0] < 0.5));      // temper.c:537-538
-                const int l = __builtin_amdgcn_readfirstlane(pick1(cu[1], k)) - 1;          // component i (0-based)
-                double lh, ly = 0.0, sco = 0.0, spr = 0.0, y[P], xi[P];
-                int m = 0, slot_ = 0;
-#pragma unroll
-                for (int j = 0; j < P; j++) xi[j] = lane_read(x[j], l);
-                const double Li = lane_read(L, l);
-                if (within) {
-                    // proposal (temper.c:1003-1024)
-                    if (sk == MCMCHIP_SCALE_FULL) {
-                        const double *scf = gscale + (slist ? (size_t)l * P * P : 0);
-#pragma unroll
-                        for (int j = 0; j < P; j++) {
-                            double yj = xi[j];
-#pragma unroll
-                            for (int i = 0; i < P; i++) yj = add_nofma(yj, mul_nofma(scf[j + P * i], cz[i]));
-                            y[j] = yj;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < P; j++) y[j] = add_nofma(xi[j], mul_nofma(lane_read(sc[j], l), cz[j]));
-                    }
-                    ly = WITCH ? witch_value<P>(lane_read(wb, l), lane_read(win, l), lane_read(wco, l), y)
-                               : lud_temper(KIND, P, gpar, k, l + 1, y);
-                    lh = ly - Li;
-                    if (ly == INFINITY || isnan(ly)) { if (lane == 0) atomicOr(q.flag, isnan(ly) ? FLAG_NAN : FLAG_POSINF); }
-                } else {
-                    const int nni = __builtin_amdgcn_readlane(nn, l);
-                    slot_ = __builtin_amdgcn_readfirstlane(pick1(cu[2], nni)) - 1;
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)nbp, l);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nbp >> 32), l);
-                    const unsigned long long row = ((unsigned long long)hi << 32) | lo;
-                    m = (int)((row >> (8 * slot_)) & 0xffu);                                // component j (0-based)
-                    double xj[P];
-#pragma unroll
-                    for (int j = 0; j < P; j++) xj[j] = lane_read(x[j], m);
-                    const double Lj = lane_read(L, m);
-                    if (WITCH) {
-                        sco = witch_value<P>(lane_read(wb, m), lane_read(win, m), lane_read(wco, m), xi);  // (j, x_i)
-                        spr = witch_value<P>(lane_read(wb, l), lane_read(win, l), lane_read(wco, l), xj);  // (i, x_j)
-                    } else {
-                        // lanes 0..31 evaluate (j, x_i), lanes 32..63 evaluate (i, x_j)
-                        const bool lowh = lane < 32;
-                        double th[P];
-#pragma unroll
-                        for (int j = 0; j < P; j++) th[j] = lowh ? xi[j] : xj[j];
-                        const double v = lud_temper(KIND, P, gpar, k, (lowh ? m : l) + 1, th);
-                        sco = lane_read(v, 0);
-                        spr = lane_read(v, 32);
-                    }
-                    lh = spr + sco - Lj - Li;                                               // temper.c:742-744
-                    if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (lane == 0) atomicOr(q.flag, FLAG_NAN); }
-#pragma unroll
-                    for (int j = 0; j < P; j++) y[j] = xj[j];
-                }
-                if (isnan(lh) || (isinf(lh) && lh > 0)) { if (lane == 0) atomicOr(q.flag, FLAG_HASTINGS); lh = -INFINITY; }
-                bool accept = true;
-                if (lh < 0.0) accept = cu[3] < exp(lh);                                     // temper.c:582-587
-                if (within) {
-                    if (lane == l) {
-                        axd++;
-                        if (accept) {
-                            axn++;
-                            L = ly;
-#pragma unroll
-                            for (int j = 0; j < P; j++) x[j] = y[j];
-                        }
-                    }
-                } else {
-                    if (accept) {
-                        if (lane == l) {
-                            L = spr;
-#pragma unroll
-                            for (int j = 0; j < P; j++) x[j] = y[j];
-                        } else if (lane == m) {
-                            L = sco;
-#pragma unroll
-                            for (int j = 0; j < P; j++) x[j] = xi[j];
-                        }
-                    }
-                    if (lane == 0) {
-                        if (accept) atomicAdd(&ain[l * maxnn + slot_], 1u);
-                        atomicAdd(&aid[l * maxnn + slot_], 1u);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) cu[j] = nu[j];
-#pragma unroll
-                for (int j = 0; j < P; j++) cz[j] = nz[j];
-            }
-            // batch accumulation once per blen step (temper.c:851-867)
-            if (!corner) {
-#pragma unroll
-                for (int j = 0; j < P; j++) acc[j] += x[j];
-            } else {                               // tests/temp-par-witch.R:52-59
-                bool all = true;
-#pragma unroll
-                for (int j = 0; j < P; j++) all &= fabs(x[j]) - wb > 0;
-                acc[0] += all ? 1.0 : 0.0;
-            }
-        }
-        if (live) {
-            if (!corner) {
-#pragma unroll
-                for (int j = 0; j < P; j++)
-                    q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * (c + k * j)] = acc[j] / q.blen;   // temper.c:871-875
-            } else {
-                q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * c] = acc[0] / q.blen;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < P; j++) acc[j] = 0.0;
-    }
-    __syncthreads();
-    if (live) {
-        q.acceptx[(size_t)e * k + c] = (double)axn / (double)axd;        // 0/0 = NaN (temper.c:889-890)
-        int slot = 0;
-        for (int j = 0; j < k; j++) {
-            double v = NAN;                                              // NA for non-neighbours (temper.c:896-897)
-            if (q.neighbors[c + k * j]) {
-                v = (double)ain[c * maxnn + slot] / (double)aid[c * maxnn + slot];
-                slot++;
-            }
-            q.accepti[(size_t)e * k * k + c + k * j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < P; j++) q.final_[(size_t)e * k * P + c + k * j] = x[j];
-    }
-}
-
-template <int P, int KIND>
-static int launch_temper_reg(const TemperDev &q, int maxnn, hipStream_t s)
-{
-    const int k = q.k;
-    TemperRegLds lay;
-    int o = 0;
-    lay.ubuf = o; o += 64 * 4;
-    lay.zbuf = o; o += 64 * ((P + 1) & ~1);
-    lay.ain = o; o += (k * maxnn + 1) / 2;
-    lay.aid = o; o += (k * maxnn + 1) / 2;
-    const long slen1h = (q.scale_kind & 7) == MCMCHIP_SCALE_FULL ? P * P : 0;     // constant / diagonal scales live in registers
-    const long nscale = (q.scale_kind & MCMCHIP_SCALE_LIST) ? slen1h * k : slen1h;
-    lay.npar_lds = (KIND != MCMCHIP_T_WITCH && q.npar > 0 && q.npar <= 2048) ? (int)q.npar : 0;
-    lay.nscale_lds = (int)nscale;
-    lay.par = o; o += lay.npar_lds;
-    lay.scale = o; o += lay.nscale_lds;
-    lay.end = o;
-    hipLaunchKernelGGL((temper_reg_kernel<P, KIND>), dim3((unsigned)q.nens), dim3(64), (size_t)o * 8, s, q, lay, maxnn);
-    HIP_TRY(hipGetLastError());
-    return MCMCHIP_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Run-parallel variant.  Elementary updates that touch DISJOINT components commute: a within-component
-// step reads and writes one row of the state, a swap two rows, and each iteration owns its own random
-// numbers (fixed Philox counters / injected slots).  So a maximal RUN of consecutive iterations whose
-// component sets are pairwise disjoint can be executed in one pass, every touched component updated by
-// its own lane at the same time; the result is the sequential one, bit for bit.  Per window of 64
-// iterations: lane t draws iteration t's numbers and decodes (within | swap, i, j, slot); a scalar scan
-// over the 64 component masks cuts the window into runs (also at batch ends); per run the iterations
-// scatter their index to their components' lanes through LDS, each such lane gathers its z / u, fetches the
-// partner row by ds_bpermute for a swap, and ONE log-density evaluation, one exp and one predicated
-// commit serve the whole run.  With k = 64 a run holds ~6 iterations.  Batch sums are added per
-// accumulation point in time order with the value each lane held at that point (before or after its
-// update), so they too equal the sequential sums exactly.
 struct TemperRunLds {
     int zbuf, u3buf, desc, own, nnT, nbT, ain, aid, par, scale, end;   // offsets in 8-byte words
     int npar_lds, nscale_lds;
@@ -652,7 +383,7 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
     const int nout = corner ? k : k * P;
     double *Zbuf = lds + lay.zbuf, *U3 = lds + lay.u3buf;
     unsigned *desc = (unsigned *)(lds + lay.desc);
-    int *own = (int *)(lds + lay.own);
+    unsigned long long *Tm = (unsigned long long *)(lds + lay.own);
     int *nnT = (int *)(lds + lay.nnT), *nbT = (int *)(lds + lay.nbT);
     unsigned *ain = (unsigned *)(lds + lay.ain), *aid = (unsigned *)(lds + lay.aid);
     const double *gpar = q.par, *gscale = q.scale;
@@ -707,6 +438,9 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
     const unsigned long long gens = q.ens_offset + (unsigned long long)e;
     const unsigned long long per = (unsigned long long)q.blen * (unsigned long long)q.nspac;   // iterations per batch
     const unsigned nspac = (unsigned)q.nspac;
+    const bool small_per = per < 0x7fffff00ull;
+    unsigned sp = 0;                       // it0 mod nspac
+    unsigned long long bp = 0;             // it0 mod per
     int kb = 0;
 
     for (long it0 = 0; it0 < niter; it0 += 64) {
@@ -739,44 +473,59 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
             t_slot = pick1(u2, nnT[t_l]) - 1;
             t_m = nbT[t_l * maxnn + t_slot];
         }
-        const unsigned long long bits = valid ? (1ull << t_l) | (1ull << t_m) : 0ull;
         // accumulation points (every nspac iterations, temper.c:851-867) and batch ends, as lane masks
-        const unsigned long long gi = (unsigned long long)it0 + (unsigned long long)lane + 1ull;
-        const unsigned long long Am = __ballot(valid && (nspac == 1u || gi % nspac == 0ull));
-        const unsigned long long Bm = __ballot(valid && gi % per == 0ull);
+        bool t_acc, t_bend;
+        if (small_per) {
+            t_acc = (sp + (unsigned)lane + 1u) % nspac == 0u;
+            t_bend = ((unsigned)bp + (unsigned)lane + 1u) % (unsigned)per == 0u;
+        } else {                                                       // per >= 2^31: at most one batch end per window
+            t_acc = (sp + (unsigned)lane + 1u) % nspac == 0u;
+            t_bend = bp + (unsigned long long)lane + 1ull == per;
+        }
+        const unsigned long long Am = __ballot(valid && t_acc);
+        const unsigned long long Bm = __ballot(valid && t_bend);
+        sp = (sp + 64u) % nspac;
+        if (small_per) bp = (unsigned long long)(((unsigned)bp + 64u) % (unsigned)per);
+        else { bp += 64ull; if (bp >= per) bp -= per; }
         __syncthreads();                                               // previous window's readers are done
 #pragma unroll
         for (int j = 0; j < PZ; j++) Zbuf[lane * PZ + j] = zt[j];
         U3[lane] = u3;
         desc[lane] = (unsigned)t_l | ((unsigned)t_m << 8) | ((unsigned)t_slot << 16) | ((unsigned)t_within << 24);
+        Tm[lane] = 0ull;
         __syncthreads();
+        // transpose "iteration t touches components {i, j}" into "component c is touched by iterations T_c"
+        if (valid) {
+            atomicOr(&Tm[t_l], 1ull << lane);
+            if (!t_within) atomicOr(&Tm[t_m], 1ull << lane);
+        }
+        __syncthreads();
+        const unsigned long long T = Tm[lane];
+        // lane as iteration: the last earlier iteration of the window that shares a component with it
+        const unsigned long long conf = (Tm[t_l] | Tm[t_m]) & ((1ull << lane) - 1ull);
+        const int prevc = conf ? 63 - __builtin_clzll(conf) : -1;
 
-        // ---- cut the window into runs of pairwise disjoint iterations and execute each run
-        unsigned long long cur = 0;
+        // ---- cut the window into maximal runs of pairwise disjoint iterations and execute each run
         int rs = 0;
-        for (int t = 0; t <= nvalid; t++) {
-            unsigned long long b = 0;
-            if (t < nvalid) {
-                const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, t);
-                const unsigned bhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), t);
-                b = ((unsigned long long)bhi << 32) | blo;
-            }
-            const bool bend_prev = t > 0 && ((Bm >> (t - 1)) & 1ull);
-            if (t > rs && (t == nvalid || bend_prev || (b & cur))) {
-                // ===== run [rs, t)
-                own[lane] = -1;
-                __syncthreads();
-                if (lane >= rs && lane < t) {
-                    own[t_l] = lane * 4 + (t_within ? 0 : 1);
-                    if (!t_within) own[t_m] = lane * 4 + 2;
-                }
-                __syncthreads();
-                const int o = own[lane];
-                const bool active = o >= 0;
-                const int ti = active ? (o >> 2) : 0;                 // this lane's iteration within the window
-                const int role = o & 3;                                // 0 within, 1 swap (component i), 2 swap (component j)
+        while (rs < nvalid) {
+            // the run ends before the first later iteration that conflicts with one inside it, after a batch end,
+            // or with the window
+            const unsigned long long cm = __ballot(prevc >= rs) & ~((2ull << rs) - 1ull);
+            int t = cm ? __builtin_ctzll(cm) : 64;
+            const unsigned long long bmr = Bm & ~((1ull << rs) - 1ull);
+            const int be = bmr ? __builtin_ctzll(bmr) + 1 : 65;
+            const bool bend_prev = be <= t;
+            if (bend_prev) t = be;
+            if (t > nvalid) t = nvalid;
+            {
+                // ===== run [rs, t): lane as component -- its first touching iteration at or after rs, if inside the run
+                const unsigned long long rem = T & ~((1ull << rs) - 1ull);
+                const int tfirst = rem ? __builtin_ctzll(rem) : 64;
+                const bool active = tfirst < t;
+                const int ti = active ? tfirst : 0;                   // this lane's iteration within the window
                 const unsigned d = desc[ti];
                 const int d_l = d & 0xff, d_m = (d >> 8) & 0xff, d_slot = (d >> 16) & 0xff;
+                const int role = (d >> 24) ? 0 : (lane == d_l ? 1 : 2);  // 0 within, 1 swap (component i), 2 swap (component j)
                 const bool sw = active && role != 0;
                 const int partner = sw ? (role == 1 ? d_m : d_l) : lane;
                 const double uh = U3[ti];
@@ -861,9 +610,7 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
                     kb++;
                 }
                 rs = t;
-                cur = 0;
             }
-            cur |= b;
         }
     }
     __syncthreads();
@@ -892,7 +639,7 @@ static int launch_temper_run(const TemperDev &q, int maxnn, hipStream_t s)
     lay.zbuf = o; o += 64 * ((P + 1) & ~1);
     lay.u3buf = o; o += 64;
     lay.desc = o; o += 32;
-    lay.own = o; o += 32;
+    lay.own = o; o += 64;
     lay.nnT = o; o += (k + 1) / 2;
     lay.nbT = o; o += (k * maxnn + 1) / 2;
     lay.ain = o; o += (k * maxnn + 1) / 2;
@@ -930,25 +677,19 @@ int launch_temper(const TemperDev &q, hipStream_t s)
         }
         maxnn = m;
     }
-    // register-resident kernel for the common parallel-tempering shape; everything else takes temper_kernel
-    const bool reg_ok = q.parallel && !q.debug && k <= 64 && p >= 1 && p <= 4 && maxnn <= 8 &&
+    // run-parallel kernel for the common parallel-tempering shape (faster than temper_kernel from k = 4 up, measured);
+    // everything else takes temper_kernel
+    const bool run_ok = q.parallel && !q.debug && k <= 64 && p >= 1 && p <= 4 && maxnn <= 8 &&
                         (q.kind == MCMCHIP_T_WITCH || q.kind == MCMCHIP_T_TEMPERED_NORMMIX);
-    if (q.path == MCMCHIP_PATH_REG && !reg_ok)
-        return set_error(MCMCHIP_EINVAL, "register tempering path needs parallel = 1, debug = 0, k <= 64, p <= 4, "
+    if (q.path == MCMCHIP_PATH_RUN && !run_ok)
+        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path needs parallel = 1, debug = 0, k <= 64, p <= 4, "
                                          "at most 8 neighbours per component and a closed-form descriptor");
-    if (q.path == MCMCHIP_PATH_RUN && !reg_ok)
-        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path has the requirements of the register tempering path");
-    if (reg_ok && q.path != MCMCHIP_PATH_LDS) {
-        // runs of disjoint iterations only pay off when there are enough components to keep them long
-        const bool runs = q.path == MCMCHIP_PATH_RUN || (q.path == MCMCHIP_PATH_AUTO && k >= 16);
-#define REG_CASE(PP) \
-        case PP: \
-            if (runs) return q.kind == MCMCHIP_T_WITCH ? launch_temper_run<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
-                                                       : launch_temper_run<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s); \
-            return q.kind == MCMCHIP_T_WITCH ? launch_temper_reg<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
-                                             : launch_temper_reg<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
-        switch (p) { REG_CASE(1) REG_CASE(2) REG_CASE(3) REG_CASE(4) }
-#undef REG_CASE
+    if (run_ok && q.path != MCMCHIP_PATH_LDS) {
+#define RUN_CASE(PP) \
+        case PP: return q.kind == MCMCHIP_T_WITCH ? launch_temper_run<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
+                                                  : launch_temper_run<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
+        switch (p) { RUN_CASE(1) RUN_CASE(2) RUN_CASE(3) RUN_CASE(4) }
+#undef RUN_CASE
     }
     const int nstate = q.parallel ? k * p : p + 1;
     const int nout = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (q.parallel ? k : 2 * k) : (q.parallel ? k * p : p);

@@ -70,7 +70,7 @@ def c4():
         oracle.temper(ot, init[:16], nb, 20, blen, nspac, 0.3, parallel=True, seed=3, nthreads=16)
         cel = time.perf_counter() - t0
         prev = None
-        for path, pname in ((abi.PATH_LDS, "lds"), (abi.PATH_REG, "reg"), (abi.PATH_RUN, "run")):
+        for path, pname in ((abi.PATH_LDS, "lds"), (abi.PATH_RUN, "run")):
             t0 = time.perf_counter()
             o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3, parallel=True, seed=3, _path=path)
             el = time.perf_counter() - t0
@@ -84,6 +84,25 @@ def c4():
                         "kernel_ensemble_iter_per_s": E * niter / (kms * 1e-3), "same_bits_as_lds_kernel": same,
                         "acceptx_mean": float(np.nanmean(o["acceptx"])), "accepti_mean": float(np.nanmean(o["accepti"])),
                         "cpu_oracle_16thr_ensemble_iter_per_s": 16 * 20 * blen * nspac / cel})
+    return out
+
+
+def c4sweep():
+    """which temper kernel wins where: witch's hat p = 3, 1024 ensembles x 6000 iterations, k and nspac varied"""
+    out = []
+    E, p = 1024, 3
+    for k in (4, 8, 16, 32, 64):
+        i, j = np.indices((k, k))
+        nb = np.abs(i - j) == 1
+        par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.linspace(0, 5, k) / p)
+        tg = api.Target(abi.T_WITCH, p, par=par)
+        init = np.zeros((E, k, p))
+        for nbatch, blen, nspac in ((60, 100, 1), (60, 5, 20)):
+            row = {"k": k, "nspac": nspac}
+            for path, pname in ((abi.PATH_LDS, "lds"), (abi.PATH_RUN, "run")):
+                api.temper(tg, init, nb, nbatch, blen, nspac, 0.3, parallel=True, seed=3, _path=path)
+                row[pname + "_ms"] = round(api.last_kernel_time()[1], 3)
+            out.append(row)
     return out
 
 
@@ -243,6 +262,6 @@ if __name__ == "__main__":
             a = [int(v) for v in w[3:].split(",")]
             r = c5(a[0], a[1], tuple(a[2:]))
         else:
-            r = {"c2": c2, "c4": c4, "c4models": c4models, "c5": c5, "c5p256": lambda: c5(2_000_000, 256)}[w]()
+            r = {"c2": c2, "c4": c4, "c4models": c4models, "c4sweep": c4sweep, "c5": c5, "c5p256": lambda: c5(2_000_000, 256)}[w]()
         for line in (r if isinstance(r, list) else [r]):
             print(json.dumps(line))

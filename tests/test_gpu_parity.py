@@ -378,9 +378,8 @@ def test_temper_philox_matches_oracle_restatement(api, oracle_mod):
 @pytest.mark.parametrize("target,p", [("witch", 1), ("witch", 3), ("witch", 4), ("mixture", 2), ("mixture", 3)])
 @pytest.mark.parametrize("k,nbrs", [(64, 1), (5, 2), (37, 4)])
 @pytest.mark.parametrize("scale_kind", ["scalar", "list_scalar", "list_vector", "matrix", "list_matrix"])
-def test_temper_register_kernel_equals_lds_kernel(api, oracle_mod, target, p, k, nbrs, scale_kind):
-    """the lane-per-component kernel (MCMCHIP_PATH_REG), the run-parallel kernel (MCMCHIP_PATH_RUN) and the LDS
-    kernel give the same bits, with injected streams and with device Philox, identity and corner-indicator output,
+def test_temper_run_kernel_equals_lds_kernel(api, oracle_mod, target, p, k, nbrs, scale_kind):
+    """the run-parallel kernel (MCMCHIP_PATH_RUN) and the LDS kernel give the same bits, with injected streams and with device Philox, identity and corner-indicator output,
     thinned and unthinned batches; spot check against the oracle"""
     rng = np.random.default_rng(k * 100 + p)
     E = 9
@@ -406,13 +405,13 @@ def test_temper_register_kernel_equals_lds_kernel(api, oracle_mod, target, p, k,
         for outfun in outs:
             for kw in (dict(unif=unif, norm=norm), dict(seed=77, ens_offset=3)):
                 a = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=abi.PATH_LDS, **kw)
-                for path in (abi.PATH_REG, abi.PATH_RUN):
+                for path in (abi.PATH_RUN,):
                     b = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, outfun=outfun, _path=path, **kw)
                     for name in ("final", "batch", "acceptx", "accepti"):
                         assert np.array_equal(a[name], b[name], equal_nan=True), (name, outfun, list(kw), path, nbatch)
     ref = oracle_mod.temper(oracle_mod.Target(K, p, par=par), init, nb, nbatch, blen, nspac, scale, parallel=True,
                             unif=unif, norm=norm)
-    for path in (abi.PATH_REG, abi.PATH_RUN):
+    for path in (abi.PATH_RUN,):
         o = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=True, unif=unif, norm=norm, _path=path)
         assert np.array_equal(o["final"], ref["final"])
         assert np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True)
@@ -420,16 +419,16 @@ def test_temper_register_kernel_equals_lds_kernel(api, oracle_mod, target, p, k,
         assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
 
 
-def test_temper_register_kernel_refuses_other_shapes(api):
+def test_temper_run_kernel_refuses_other_shapes(api):
     k, p = 4, 3
     par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
     i, j = np.indices((k, k))
     nb = np.abs(i - j) == 1
     tg = api.Target(abi.T_WITCH, p, par=par)
-    with pytest.raises(Exception, match="register tempering path"):
-        api.temper(tg, np.array([1.0, 0, 0, 0]), nb, 5, 1, 1, 0.3, parallel=False, seed=1, _path=abi.PATH_REG)
-    with pytest.raises(Exception, match="register tempering path"):
-        api.temper(tg, np.zeros((k, p)), nb, 5, 1, 1, 0.3, parallel=True, debug=True, seed=1, _path=abi.PATH_REG)
+    with pytest.raises(Exception, match="run-parallel tempering path"):
+        api.temper(tg, np.array([1.0, 0, 0, 0]), nb, 5, 1, 1, 0.3, parallel=False, seed=1, _path=abi.PATH_RUN)
+    with pytest.raises(Exception, match="run-parallel tempering path"):
+        api.temper(tg, np.zeros((k, p)), nb, 5, 1, 1, 0.3, parallel=True, debug=True, seed=1, _path=abi.PATH_RUN)
 
 
 # ----------------------------------------------------------------------------- initseq / olbm
