@@ -15,17 +15,19 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     k = int(rng.choice([2, 3, 6, 17, 64]))
-    p = int(rng.choice([1, 2, 3, 5, 9, 16]))
+    p = int(rng.choice([1, 2, 3, 4, 5, 9, 16]))
     E = int(rng.choice([1, 3, 8]))
     parallel = bool(rng.integers(2))
     debug = bool(rng.integers(2))
     nbatch, blen, nspac = int(rng.integers(1, 8)), int(rng.integers(1, 6)), int(rng.integers(1, 4))
+    if rng.integers(3) == 0:                                # several 64-iteration windows of the run-parallel kernel
+        nbatch, blen, nspac = int(rng.integers(1, 40)), int(rng.integers(1, 9)), int(rng.integers(1, 6))
     niter = nbatch * blen * nspac
     nb = np.zeros((k, k), dtype=bool)                       # random connected symmetric graph
     for i in range(1, k):
         j = int(rng.integers(0, i))
         nb[i, j] = nb[j, i] = True
-    extra = rng.random((k, k)) < 0.15
+    extra = rng.random((k, k)) < float(rng.choice([0.0, 0.02, 0.15]))
     nb |= np.triu(extra, 1) | np.triu(extra, 1).T
     kind = str(rng.choice(["witch", "mixture", "models"]))
     out_kind, outfun = oracle.TOUT_NONE, None
