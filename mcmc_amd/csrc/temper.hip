@@ -366,63 +366,164 @@ template <int P> __device__ __forceinline__ double witch_value(double bnd, doubl
 }
 
 struct TemperRunLds {
-    int zbuf, u3buf, desc, own, nnT, nbT, ain, aid, par, scale, end;   // offsets in 8-byte words
+    // offsets in 8-byte words; the window buffers (zbuf .. hdr) exist twice, `wstride` words apart
+    int zbuf, u3buf, desc, tm, prevc, hdr, wstride, nnT, nbT, ain, aid, par, scale, end;
     int npar_lds, nscale_lds;
 };
 
+// wavefront-scope hand-over inside one wavefront's private LDS traffic (LDS operations of a wavefront complete in order)
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
+// Three wavefronts per ensemble: wave 0 CONSUMES window w (owns the state, executes the runs) while wave 1 draws the
+// uniforms of window w+1, decodes the moves and builds the run masks, and wave 2 draws its normals; the window
+// buffers are double-buffered in LDS and the three meet at one workgroup barrier per window.
 template <int P, int KIND>
-__global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLds lay, int maxnn)
+__global__ __launch_bounds__(192) void temper_run_kernel(TemperDev q, TemperRunLds lay, int maxnn)
 {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long e = blockIdx.x;
     const int k = q.k;
     constexpr int PZ = (P + 1) & ~1;
     constexpr bool WITCH = KIND == MCMCHIP_T_WITCH;
     const bool corner = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER;
     const int nout = corner ? k : k * P;
-    double *Zbuf = lds + lay.zbuf, *U3 = lds + lay.u3buf;
-    unsigned *desc = (unsigned *)(lds + lay.desc);
-    unsigned long long *Tm = (unsigned long long *)(lds + lay.own);
     int *nnT = (int *)(lds + lay.nnT), *nbT = (int *)(lds + lay.nbT);
     unsigned *ain = (unsigned *)(lds + lay.ain), *aid = (unsigned *)(lds + lay.aid);
     const double *gpar = q.par, *gscale = q.scale;
     if (lay.npar_lds > 0) {
         double *lp = lds + lay.par;
-        for (int i = lane; i < lay.npar_lds; i += 64) lp[i] = q.par[i];
+        for (int i = threadIdx.x; i < lay.npar_lds; i += 192) lp[i] = q.par[i];
         gpar = lp;
     }
     if (lay.nscale_lds > 0) {
         double *ls = lds + lay.scale;
-        for (int i = lane; i < lay.nscale_lds; i += 64) ls[i] = q.scale[i];
+        for (int i = threadIdx.x; i < lay.nscale_lds; i += 192) ls[i] = q.scale[i];
         gscale = ls;
     }
-    for (int i = lane; i < k * maxnn; i += 64) ain[i] = aid[i] = 0;
+    for (int i = threadIdx.x; i < k * maxnn; i += 192) ain[i] = aid[i] = 0;
     const bool live = lane < k;
     const int c = live ? lane : 0;                 // idle lanes shadow component 0 and never commit
     const int sk = q.scale_kind & 7;
     const bool slist = (q.scale_kind & MCMCHIP_SCALE_LIST) != 0;
     const bool inj = q.rng_mode == MCMCHIP_RNG_INJECTED;
-
-    double x[P], acc[P], sc[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-        x[j] = q.initial[(size_t)e * k * P + c + k * j];
-        acc[j] = 0.0;
-        sc[j] = sk == MCMCHIP_SCALE_CONSTANT ? q.scale[slist ? c : 0]
-              : sk == MCMCHIP_SCALE_DIAGONAL ? q.scale[(slist ? c * P : 0) + j] : 0.0;
-    }
-    const double *scf = gscale + (slist ? (size_t)c * P * P : 0);      // full-matrix scale of this lane's component
-    if (live) {
+    if (wave == 0 && live) {
         int n = 0;
         for (int j = 0; j < k; j++)
             if (q.neighbors[c + k * j]) nbT[c * maxnn + n++] = j;     // ascending (temper.c:504-510)
         nnT[c] = n;
     }
+    __syncthreads();
+
+    const long niter = (long)q.nbatch * q.blen * q.nspac;
+    const long nwin = (niter + 63) / 64;
+    const unsigned long long gens = q.ens_offset + (unsigned long long)e;
+    const unsigned long long per = (unsigned long long)q.blen * (unsigned long long)q.nspac;   // iterations per batch
+    const unsigned nspac = (unsigned)q.nspac;
+    const bool small_per = per < 0x7fffff00ull;
+
+    if (wave != 0) {
+        // ================= producers =================
+        unsigned sp = 0;                       // it0 mod nspac   (wave 1)
+        unsigned long long bp = 0;             // it0 mod per
+        for (long w = 0; w < nwin; w++) {
+            double *wb_ = lds + (w & 1) * lay.wstride;
+            const long it0 = w * 64;
+            const int nvalid = (int)(niter - it0 < 64 ? niter - it0 : 64);
+            const bool valid = lane < nvalid;
+            const unsigned long long g2 = q.iter_offset + (unsigned long long)it0 + (unsigned long long)lane;
+            if (wave == 2) {
+                // ---- lane t: the normals of iteration it0 + t
+                double zt[PZ];
+#pragma unroll
+                for (int j = 0; j < PZ; j++) zt[j] = 0.0;
+                if (valid) {
+                    if (inj) {
+                        const double *zp = q.norm + ((size_t)e * niter + it0 + lane) * P;
+#pragma unroll
+                        for (int j = 0; j < P; j++) zt[j] = zp[j];
+                    } else {
+#pragma unroll
+                        for (int j2 = 0; 2 * j2 < P; j2++)
+                            philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, g2, (uint32_t)(2 + j2), zt[2 * j2], zt[2 * j2 + 1]);
+                    }
+                }
+                double *Zb = wb_ + lay.zbuf;
+#pragma unroll
+                for (int j = 0; j < PZ; j++) Zb[lane * PZ + j] = zt[j];
+            } else {
+                // ---- lane t: the uniforms and the decoded move of iteration it0 + t
+                double u0 = 1.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+                if (valid) {
+                    if (inj) {
+                        const double *up = q.unif + ((size_t)e * niter + it0 + lane) * 4;
+                        u0 = up[0]; u1 = up[1]; u2 = up[2]; u3 = up[3];
+                    } else {
+                        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 0u, u0, u1);
+                        philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 1u, u2, u3);
+                    }
+                }
+                const bool t_within = u0 < 0.5;                        // temper.c:537-538
+                const int t_l = valid ? pick1(u1, k) - 1 : 0;
+                int t_m = t_l, t_slot = 0;
+                if (valid && !t_within) {
+                    t_slot = pick1(u2, nnT[t_l]) - 1;
+                    t_m = nbT[t_l * maxnn + t_slot];
+                }
+                // accumulation points (every nspac iterations, temper.c:851-867) and batch ends, as lane masks
+                const bool t_acc = (sp + (unsigned)lane + 1u) % nspac == 0u;
+                const bool t_bend = small_per ? ((unsigned)bp + (unsigned)lane + 1u) % (unsigned)per == 0u
+                                              : bp + (unsigned long long)lane + 1ull == per;   // per >= 2^31: one per window at most
+                const unsigned long long Am = __ballot(valid && t_acc);
+                const unsigned long long Bm = __ballot(valid && t_bend);
+                sp = (sp + 64u) % nspac;
+                if (small_per) bp = (unsigned long long)(((unsigned)bp + 64u) % (unsigned)per);
+                else { bp += 64ull; if (bp >= per) bp -= per; }
+                unsigned long long *Tm = (unsigned long long *)(wb_ + lay.tm);
+                (wb_ + lay.u3buf)[lane] = u3;
+                ((unsigned *)(wb_ + lay.desc))[lane] =
+                    (unsigned)t_l | ((unsigned)t_m << 8) | ((unsigned)t_slot << 16) | ((unsigned)t_within << 24);
+                Tm[lane] = 0ull;
+                WAVE_SYNC();
+                // transpose "iteration t touches components {i, j}" into "component c is touched by iterations T_c"
+                if (valid) {
+                    atomicOr(&Tm[t_l], 1ull << lane);
+                    if (!t_within) atomicOr(&Tm[t_m], 1ull << lane);
+                }
+                WAVE_SYNC();
+                // the last earlier iteration of the window that shares a component with iteration t
+                const unsigned long long conf = (Tm[t_l] | Tm[t_m]) & ((1ull << lane) - 1ull);
+                ((int *)(wb_ + lay.prevc))[lane] = conf ? 63 - __builtin_clzll(conf) : -1;
+                if (lane == 0) {
+                    unsigned long long *h = (unsigned long long *)(wb_ + lay.hdr);
+                    h[0] = Am; h[1] = Bm;
+                }
+            }
+            __syncthreads();               // window w handed over (the consumer is one window behind)
+        }
+        __syncthreads();                   // the consumer's last window
+        return;
+    }
+
+    // ================= consumer =================
+    double x[P], acc[P], sc[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        x[j] = q.initial[(size_t)e * k * P + c + k * j];
+        acc[j] = 0.0;
+        // constant scale = diagonal scale with equal entries (same multiply, same add)
+        sc[j] = sk == MCMCHIP_SCALE_CONSTANT ? q.scale[slist ? c : 0]
+              : sk == MCMCHIP_SCALE_DIAGONAL ? q.scale[(slist ? c * P : 0) + j] : 0.0;
+    }
+    const double *scf = gscale + (slist ? (size_t)c * P * P : 0);      // full-matrix scale of this lane's component
     unsigned axn = 0, axd = 0;
     double wb = 0.0, win = 0.0, wco = 0.0;
     if (WITCH) { wb = q.par[c]; win = q.par[k + c]; wco = q.par[2 * k + c]; }
-    __syncthreads();
     auto LUD_OWN = [&](const double *th) -> double {                  // log density of (component c, th)
         if (WITCH) return witch_value<P>(wb, win, wco, th);
         return lud_temper(KIND, P, gpar, k, c + 1, th);
@@ -433,77 +534,28 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
         else if (L == INFINITY) atomicOr(q.flag, FLAG_POSINF);
         else if (isnan(L)) atomicOr(q.flag, FLAG_NAN);
     }
-
-    const long niter = (long)q.nbatch * q.blen * q.nspac;
-    const unsigned long long gens = q.ens_offset + (unsigned long long)e;
-    const unsigned long long per = (unsigned long long)q.blen * (unsigned long long)q.nspac;   // iterations per batch
-    const unsigned nspac = (unsigned)q.nspac;
-    const bool small_per = per < 0x7fffff00ull;
-    unsigned sp = 0;                       // it0 mod nspac
-    unsigned long long bp = 0;             // it0 mod per
     int kb = 0;
-
-    for (long it0 = 0; it0 < niter; it0 += 64) {
+    __syncthreads();                       // window 0 is ready
+    for (long w = 0; w < nwin; w++) {
+        const double *wb_ = lds + (w & 1) * lay.wstride;
+        const double *Zbuf = wb_ + lay.zbuf, *U3 = wb_ + lay.u3buf;
+        const unsigned *desc = (const unsigned *)(wb_ + lay.desc);
+        const long it0 = w * 64;
         const int nvalid = (int)(niter - it0 < 64 ? niter - it0 : 64);
-        const bool valid = lane < nvalid;
-        // ---- lane t: the draws and the decoded move of iteration it0 + t
-        double u0 = 1.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, zt[PZ];
+        const unsigned long long T = ((const unsigned long long *)(wb_ + lay.tm))[lane];
+        const int prevc = ((const int *)(wb_ + lay.prevc))[lane];
+        const unsigned long long *h = (const unsigned long long *)(wb_ + lay.hdr);
+        const unsigned long long Am = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)h[0]) |
+                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(h[0] >> 32)) << 32);
+        const unsigned long long Bm = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)h[1]) |
+                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(h[1] >> 32)) << 32);
+
+        // this lane's (component's) first touching iteration of the window and its draws
+        int nti = T ? __builtin_ctzll(T) : 64;
+        unsigned cd = desc[nti & 63];
+        double cuh = U3[nti & 63], cz[P];
 #pragma unroll
-        for (int j = 0; j < PZ; j++) zt[j] = 0.0;
-        if (valid) {
-            if (inj) {
-                const double *up = q.unif + ((size_t)e * niter + it0 + lane) * 4;
-                u0 = up[0]; u1 = up[1]; u2 = up[2]; u3 = up[3];
-                const double *zp = q.norm + ((size_t)e * niter + it0 + lane) * P;
-#pragma unroll
-                for (int j = 0; j < P; j++) zt[j] = zp[j];
-            } else {
-                const unsigned long long g2 = q.iter_offset + (unsigned long long)it0 + (unsigned long long)lane;
-                philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 0u, u0, u1);
-                philox_u2(q.seed, PHILOX_TAG_TEMPER, gens, g2, 1u, u2, u3);
-#pragma unroll
-                for (int j2 = 0; 2 * j2 < P; j2++)
-                    philox_n2(q.seed, PHILOX_TAG_TEMPER, gens, g2, (uint32_t)(2 + j2), zt[2 * j2], zt[2 * j2 + 1]);
-            }
-        }
-        const bool t_within = u0 < 0.5;                                // temper.c:537-538
-        const int t_l = valid ? pick1(u1, k) - 1 : 0;
-        int t_m = t_l, t_slot = 0;
-        if (valid && !t_within) {
-            t_slot = pick1(u2, nnT[t_l]) - 1;
-            t_m = nbT[t_l * maxnn + t_slot];
-        }
-        // accumulation points (every nspac iterations, temper.c:851-867) and batch ends, as lane masks
-        bool t_acc, t_bend;
-        if (small_per) {
-            t_acc = (sp + (unsigned)lane + 1u) % nspac == 0u;
-            t_bend = ((unsigned)bp + (unsigned)lane + 1u) % (unsigned)per == 0u;
-        } else {                                                       // per >= 2^31: at most one batch end per window
-            t_acc = (sp + (unsigned)lane + 1u) % nspac == 0u;
-            t_bend = bp + (unsigned long long)lane + 1ull == per;
-        }
-        const unsigned long long Am = __ballot(valid && t_acc);
-        const unsigned long long Bm = __ballot(valid && t_bend);
-        sp = (sp + 64u) % nspac;
-        if (small_per) bp = (unsigned long long)(((unsigned)bp + 64u) % (unsigned)per);
-        else { bp += 64ull; if (bp >= per) bp -= per; }
-        __syncthreads();                                               // previous window's readers are done
-#pragma unroll
-        for (int j = 0; j < PZ; j++) Zbuf[lane * PZ + j] = zt[j];
-        U3[lane] = u3;
-        desc[lane] = (unsigned)t_l | ((unsigned)t_m << 8) | ((unsigned)t_slot << 16) | ((unsigned)t_within << 24);
-        Tm[lane] = 0ull;
-        __syncthreads();
-        // transpose "iteration t touches components {i, j}" into "component c is touched by iterations T_c"
-        if (valid) {
-            atomicOr(&Tm[t_l], 1ull << lane);
-            if (!t_within) atomicOr(&Tm[t_m], 1ull << lane);
-        }
-        __syncthreads();
-        const unsigned long long T = Tm[lane];
-        // lane as iteration: the last earlier iteration of the window that shares a component with it
-        const unsigned long long conf = (Tm[t_l] | Tm[t_m]) & ((1ull << lane) - 1ull);
-        const int prevc = conf ? 63 - __builtin_clzll(conf) : -1;
+        for (int j = 0; j < P; j++) cz[j] = Zbuf[(nti & 63) * PZ + j];
 
         // ---- cut the window into maximal runs of pairwise disjoint iterations and execute each run
         int rs = 0;
@@ -518,53 +570,70 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
             if (bend_prev) t = be;
             if (t > nvalid) t = nvalid;
             {
-                // ===== run [rs, t): lane as component -- its first touching iteration at or after rs, if inside the run
-                const unsigned long long rem = T & ~((1ull << rs) - 1ull);
-                const int tfirst = rem ? __builtin_ctzll(rem) : 64;
-                const bool active = tfirst < t;
-                const int ti = active ? tfirst : 0;                   // this lane's iteration within the window
-                const unsigned d = desc[ti];
-                const int d_l = d & 0xff, d_m = (d >> 8) & 0xff, d_slot = (d >> 16) & 0xff;
-                const int role = (d >> 24) ? 0 : (lane == d_l ? 1 : 2);  // 0 within, 1 swap (component i), 2 swap (component j)
+                // ===== run [rs, t): lane as component -- nti is its first touching iteration at or after rs
+                // (64: none), already fetched; it takes part if that iteration lies inside the run
+                const bool active = nti < t;
+                const int ti = nti;
+                const int d_l = cd & 0xff, d_m = (cd >> 8) & 0xff, d_slot = (cd >> 16) & 0xff;
+                const int role = (cd >> 24) ? 0 : (lane == d_l ? 1 : 2);  // 0 within, 1 swap (component i), 2 swap (component j)
                 const bool sw = active && role != 0;
                 const int partner = sw ? (role == 1 ? d_m : d_l) : lane;
-                const double uh = U3[ti];
                 double xq[P], th[P], xold[P];
 #pragma unroll
                 for (int j = 0; j < P; j++) { xq[j] = __shfl(x[j], partner); xold[j] = x[j]; }
                 const double Lq = __shfl(L, partner);
+                // while the exchange is in flight: fetch the draws of this lane's NEXT touching iteration
+                const unsigned long long rem2 = T & ~((2ull << (ti & 63)) - 1ull);
+                const int nti2 = (active && rem2) ? __builtin_ctzll(rem2) : 64;
+                const int tl = nti2 & 63;
+                const unsigned nd = desc[tl];
+                const double nuh = U3[tl];
+                double nz[P];
+#pragma unroll
+                for (int j = 0; j < P; j++) nz[j] = Zbuf[tl * PZ + j];
                 // within: proposal (temper.c:1003-1024); swap: the partner's row
                 if (sk == MCMCHIP_SCALE_FULL) {
 #pragma unroll
                     for (int j = 0; j < P; j++) {
                         double yj = x[j];
 #pragma unroll
-                        for (int i = 0; i < P; i++) yj = add_nofma(yj, mul_nofma(scf[j + P * i], Zbuf[ti * PZ + i]));
+                        for (int i = 0; i < P; i++) yj = add_nofma(yj, mul_nofma(scf[j + P * i], cz[i]));
                         th[j] = sw ? xq[j] : yj;
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < P; j++) {
-                        const double yj = add_nofma(x[j], mul_nofma(sc[j], Zbuf[ti * PZ + j]));
+                        const double yj = add_nofma(x[j], mul_nofma(sc[j], cz[j]));
                         th[j] = sw ? xq[j] : yj;
                     }
                 }
                 const double v = LUD_OWN(th);     // within: lud(i, y); swap: lud(own component, partner's row)
                 const double vq = __shfl(v, partner);
-                double lh;
-                if (sw) {
-                    const double spr = role == 1 ? v : vq;            // (i, x_j)
-                    const double sco = role == 1 ? vq : v;            // (j, x_i)
-                    const double Li = role == 1 ? L : Lq, Lj = role == 1 ? Lq : L;
-                    lh = spr + sco - Lj - Li;                          // temper.c:742-744
-                    if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (role == 1) atomicOr(q.flag, FLAG_NAN); }
-                } else {
-                    lh = v - L;
-                    if (active && (v == INFINITY || isnan(v))) atomicOr(q.flag, isnan(v) ? FLAG_NAN : FLAG_POSINF);
+                const double spr = role == 1 ? v : vq;                // (i, x_j)
+                const double sco = role == 1 ? vq : v;                // (j, x_i)
+                const double Li = role == 1 ? L : Lq, Lj = role == 1 ? Lq : L;
+                double lh = sw ? spr + sco - Lj - Li : v - L;          // temper.c:742-744 | 574-580
+                // every error case of the reference (a +Inf or NaN density, a NaN or +Inf Hastings ratio) ends in
+                // a ratio that is not < +Inf: one test on the fast path, the exact flags on the rare one
+                const bool bad = !(lh < INFINITY);
+                if (__any(active && bad)) {
+                    if (sw) {
+                        if (isnan(sco) || isnan(spr) || sco == INFINITY || spr == INFINITY) { if (role == 1) atomicOr(q.flag, FLAG_NAN); }
+                    } else if (active && (v == INFINITY || isnan(v))) atomicOr(q.flag, isnan(v) ? FLAG_NAN : FLAG_POSINF);
+                    if (bad && active && role != 2) atomicOr(q.flag, FLAG_HASTINGS);
                 }
-                if (isnan(lh) || (isinf(lh) && lh > 0)) { if (active && role != 2) atomicOr(q.flag, FLAG_HASTINGS); lh = -INFINITY; }
+                if (bad) lh = -INFINITY;
+                // accept iff lh >= 0 or u < exp(lh) (temper.c:582-587).  A single-precision exp (relative error
+                // < 2e-5 on [-80, 0]) settles every decision whose u lies outside a 1e-4 band around it; only
+                // a lane inside the band sends the run through the double-precision exp.  Same decisions.
                 bool accept = true;
-                if (lh < 0.0) accept = uh < exp(lh);                   // temper.c:582-587
+                if (lh < 0.0) {
+                    const double ef = (double)__expf((float)lh);
+                    const bool far = lh > -80.0;
+                    const bool sure = far ? (cuh < ef * (1.0 - 1e-4) || cuh > ef * (1.0 + 1e-4)) : (cuh > 1e-30);
+                    accept = far && cuh < ef;
+                    if (__any(active && !sure)) accept = cuh < exp(lh);
+                }
                 if (active) {
                     if (accept) {
                         L = v;
@@ -576,6 +645,9 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
                         if (accept) atomicAdd(&ain[lane * maxnn + d_slot], 1u);
                         atomicAdd(&aid[lane * maxnn + d_slot], 1u);
                     }
+                    nti = nti2; cd = nd; cuh = nuh;
+#pragma unroll
+                    for (int j = 0; j < P; j++) cz[j] = nz[j];
                 }
                 // batch sums: the accumulation points of the run in time order, each with the value this lane
                 // held at that point (its update happens at iteration ti)
@@ -612,8 +684,8 @@ __global__ __launch_bounds__(64) void temper_run_kernel(TemperDev q, TemperRunLd
                 rs = t;
             }
         }
+        __syncthreads();                   // window w consumed; window w+1 is ready
     }
-    __syncthreads();
     if (live) {
         q.acceptx[(size_t)e * k + c] = (double)axn / (double)axd;        // 0/0 = NaN (temper.c:889-890)
         int slot = 0;
@@ -639,19 +711,23 @@ static int launch_temper_run(const TemperDev &q, int maxnn, hipStream_t s)
     lay.zbuf = o; o += 64 * ((P + 1) & ~1);
     lay.u3buf = o; o += 64;
     lay.desc = o; o += 32;
-    lay.own = o; o += 64;
+    lay.tm = o; o += 64;
+    lay.prevc = o; o += 32;
+    lay.hdr = o; o += 2;
+    lay.wstride = o;
+    o *= 2;                                                             // two window buffers
     lay.nnT = o; o += (k + 1) / 2;
     lay.nbT = o; o += (k * maxnn + 1) / 2;
     lay.ain = o; o += (k * maxnn + 1) / 2;
     lay.aid = o; o += (k * maxnn + 1) / 2;
-    const long slen1h = (q.scale_kind & 7) == MCMCHIP_SCALE_FULL ? P * P : 0;
+    const long slen1h = (q.scale_kind & 7) == MCMCHIP_SCALE_FULL ? P * P : 0;     // constant / diagonal scales live in registers
     const long nscale = (q.scale_kind & MCMCHIP_SCALE_LIST) ? slen1h * k : slen1h;
     lay.npar_lds = (KIND != MCMCHIP_T_WITCH && q.npar > 0 && q.npar <= 2048) ? (int)q.npar : 0;
     lay.nscale_lds = (int)nscale;
     lay.par = o; o += lay.npar_lds;
     lay.scale = o; o += lay.nscale_lds;
     lay.end = o;
-    hipLaunchKernelGGL((temper_run_kernel<P, KIND>), dim3((unsigned)q.nens), dim3(64), (size_t)o * 8, s, q, lay, maxnn);
+    hipLaunchKernelGGL((temper_run_kernel<P, KIND>), dim3((unsigned)q.nens), dim3(192), (size_t)o * 8, s, q, lay, maxnn);
     HIP_TRY(hipGetLastError());
     return MCMCHIP_OK;
 }
