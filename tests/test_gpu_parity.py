@@ -15,6 +15,7 @@ from rhelpers import GOLDEN, glm_binomial, load_logit
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-12
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -932,3 +933,42 @@ def test_metrop_device_reproduces_reference_transcripts(api, oracle_mod):
         o, ref = _replay_metrop(api, oracle_mod, c_d, c_o, x, 1000, 1, sc, rs)
         assert o["accept"][0] == expect
         x = ref["final"][0]
+
+
+# ----------------------------------------------------------------------------- the C-ABI from plain C
+def test_c_demo_matches_python_api(api, tmp_path):
+    """examples/capi_demo.c (gcc, only include/mcmchip.h) drives metrop / initseq / olbm through the C-ABI; the Python
+    mirror with the same inputs and Philox seed must give the same bits (same library underneath)"""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "capi_demo")
+    assert os.path.exists(exe), "build it first: make -C examples (done by __graft_entry__.build())"
+    rng = np.random.default_rng(5)
+    n, d, C, nbatch, blen, seed = 300, 4, 6, 60, 7, 20240611
+    X = np.column_stack([np.ones(n), rng.standard_normal((n, d - 1))])
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ np.array([0.3, -0.5, 0.2, 0.1])))).astype(float)
+    data = tmp_path / "data.bin"
+    with open(data, "wb") as f:
+        np.ascontiguousarray(X).tofile(f)
+        y.tofile(f)
+    out = subprocess.run([exe, str(data), str(n), str(d), str(C), str(nbatch), str(blen), str(seed)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        name, _, rest = line.partition(":")
+        got[name] = rest.strip()
+    vec = lambda k: np.array([float(v) for v in got[k].split()])
+    assert got["error"] == 'argument "nbatch" must be positive'                 # metrop.c:60-61
+    o = api.metrop(api.logistic_target(X, y), np.zeros((C, d)), nbatch, blen, 1, scale=0.4, seed=seed, path=abi.PATH_STREAM)
+    assert np.array_equal(vec("accept"), o["accept"])
+    assert np.array_equal(vec("final"), o["final"].ravel())
+    b0 = o["batch"][0]                                                           # nbatch x d
+    r = api.initseq(b0[:, 0])                  # centres with numpy's mean, the demo with a running sum: ulps apart
+    assert int(got["initseq.m"]) == len(r["Gamma.pos"])
+    assert np.allclose(vec("gamma0"), [r["gamma0"]], rtol=1e-10, atol=0)
+    assert np.allclose(vec("Gamma.pos"), r["Gamma.pos"], rtol=1e-10, atol=1e-18)
+    assert np.allclose(vec("Gamma.con"), r["Gamma.con"], rtol=1e-10, atol=1e-18)
+    assert np.allclose(vec("var.con"), [r["var.con"]], rtol=1e-10, atol=0)
+    v = api.olbm(b0, nbatch // 5, demean=False)                                  # both let the device compute the means
+    assert np.array_equal(vec("olbm.var"), np.asarray(v).ravel(order="F"))
+    assert np.allclose(vec("olbm.mean"), b0.mean(axis=0), rtol=1e-13, atol=0)

@@ -215,3 +215,11 @@ def test_shard_range():
     from mcmc_amd.dist import shard_range
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert [shard_range(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def test_plain_c_client_builds():
+    """examples/capi_demo.c: the header is valid C99 and a gcc-built client links against libmcmchip.so"""
+    import subprocess
+    ex = os.path.join(ROOT, "examples")
+    subprocess.check_call(["make", "-s", "-B", "-C", ex])
+    assert os.access(os.path.join(ex, "capi_demo"), os.X_OK)
