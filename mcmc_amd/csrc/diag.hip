@@ -179,9 +179,10 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
     const long nblk = (len + 16 + span - 1) / span;
     if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
     // The stopping lag (first negative Gamma, initseq.c:42-46) is data dependent, so lags are produced
-    // speculatively in units of 64: every column starts with one unit and, while still active, gets as
-    // many new lags as it already has (at most 1024 per launch): at most ~2x the lag products a
-    // clairvoyant run would need.  Four consecutive units of a column go to one 256-lag work item.
+    // speculatively in units of 64: every column starts with one unit and, while still active, gets the
+    // lags a geometric extrapolation of its Gamma sequence predicts (after three rounds: as many new lags
+    // as it already has), at most 1024 per launch.  Four consecutive units of a column go to one 256-lag
+    // work item.
     const long MAX_UNITS_PER_LAUNCH = 16;
     size_t cap_units = 0;
     DevBuf partial, sums, dcols, dlags, dunits;
@@ -189,6 +190,7 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
     std::vector<long> done((size_t)ncol, -1);            // output length once the stop rule fired
     std::vector<long> have((size_t)ncol, 0);             // lags computed so far
     std::vector<double> g0((size_t)ncol, 0.0);
+    std::vector<int> rounds((size_t)ncol, 0);            // launches a column has taken part in
     std::vector<int> active;
     for (long c = 0; c < ncol; c++) active.push_back((int)c);
     std::vector<double> host;
@@ -201,7 +203,19 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
         unit_col.clear();
         for (int w = 0; w < 2; w++) { item_col[w].clear(); item_unit[w].clear(); item_lag[w].clear(); }
         for (int c : active) {
-            long nb = have[(size_t)c] == 0 ? 1 : have[(size_t)c] / IS_B;
+            long nb = have[(size_t)c] == 0 ? 1 : have[(size_t)c] / IS_B;       // default: double
+            // Where will the stop rule fire?  Gamma_k of a geometrically mixing chain decays like r^k and the rule
+            // fires once it reaches the noise floor, ~ Gamma_0 / sqrt(len): extrapolate the decay seen so far and
+            // ask for that many lags (+25 %).  Only the amount of speculative work depends on this guess.
+            const std::vector<double> &G = Gam[(size_t)c];
+            if (!G.empty() && rounds[(size_t)c] < 3 && G.front() > 0.0 && G.back() > 0.0 && G.back() < G.front()) {
+                const double decay = std::log(G.front() / G.back()) / (double)G.size();      // per lag pair
+                const double kstar = 0.5 * std::log((double)len) / decay;                    // pairs to the noise floor
+                const double want = 2.5 * kstar - (double)have[(size_t)c];                   // lags still to compute
+                nb = want > 0.0 ? (long)std::ceil(want / IS_B) : 1;
+                if (nb < 1) nb = 1;
+            }
+            rounds[(size_t)c]++;
             if (nb > MAX_UNITS_PER_LAUNCH) nb = MAX_UNITS_PER_LAUNCH;
             const long need = (2 * half - have[(size_t)c] + IS_B - 1) / IS_B;   // never past lag 2*half
             if (nb > need) nb = need;
