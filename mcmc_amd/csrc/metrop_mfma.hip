@@ -103,6 +103,10 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifndef IL_V
+#define IL_V 4
+#define IL_D 1
+#endif
 template <int KS, int NC, int NW, int TC>
 __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__restrict__ xt,
                                                                const double *__restrict__ prop, long ldc,
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         }
     };
 
+    const double sp_shift = softplus_lds_shift(sTab);
     double sum[NC];               // sum of M(eta) = |eta|/2 + L(|eta|)
 #pragma unroll
     for (int c = 0; c < NC; c++) sum[c] = 0.0;
@@ -155,9 +160,9 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the table
 
     // One tile = KS*NC MFMAs into a fresh accumulator set.  The softplus epilogue of a tile (softplus.h: per
-    // value 10 VALU instructions + the add below and 4 ds_read_b128) is software-pipelined one tile behind: it is
+    // value 10 VALU instructions + the running sum and 4 ds_read_b128) is software-pipelined one tile behind: it is
     // issued in the same basic block as the NEXT tile's MFMAs and spread between them with sched_group_barrier,
-    // so the latency of its table reads is covered by MFMAs in flight (measured: 156.8 -> 152.3 ms per launch;
+    // so the latency of its table reads is covered by MFMAs in flight (measured: 156.8 -> 152.3 ms per launch, and 147.3 -> 144.5 with the reads two values ahead;
     // its VALU instructions themselves cannot overlap the fp64 MFMA, see softplus.h).
     auto mfma_tile = [&](const double *xs, int tt, double4_t *acc) {
 #pragma unroll
@@ -173,21 +178,31 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     // min(eta,0) - L(|eta|) = eta/2 - M(eta): sum(eta) is linear in Theta (colsum . theta, added by the update
     // kernel), so only M(eta) = |eta|/2 + L(|eta|) is accumulated here
     auto epilogue = [&](const double4_t *acc) {
+        // the table reads of value v + SP_AHEAD are issued before value v is evaluated: with the one-MFMA distance the
+        // scheduler otherwise leaves between a read and its use, the LDS latency showed as s_waitcnt stalls
+        constexpr int NV = 4 * NC, SP_AHEAD = 2;
+        uint32_t addr[NV];
+        SoftplusRec rec[NV];
 #pragma unroll
-        for (int c = 0; c < NC; c++)
+        for (int v = 0; v < NV; v++) addr[v] = softplus_lds_addr(acc[v / 4][v % 4], sp_shift);
 #pragma unroll
-            for (int r = 0; r < 4; r++) sum[c] += softplus_half_abs(acc[c][r], sTab);
+        for (int v = 0; v < SP_AHEAD && v < NV; v++) softplus_lds_load(addr[v], rec[v]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            if (v + SP_AHEAD < NV) softplus_lds_load(addr[v + SP_AHEAD], rec[v + SP_AHEAD]);
+            sum[v / 4] += softplus_lds_eval(acc[v / 4][v % 4], rec[v]);
+        }
     };
     auto interleave = [&]() {
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // the first X fragments
 #pragma unroll
         for (int i = 0; i < KS * NC / 2; i++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // four VALU of the trailing epilogue
+            __builtin_amdgcn_sched_group_barrier(0x002, IL_V, 0);  // VALU of the trailing epilogue
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // LDS reads: table pairs, X fragments
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, IL_V, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, IL_D, 0);
         }
     };
 
