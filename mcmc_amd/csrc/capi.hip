@@ -349,6 +349,8 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
     p.prior_c = t->prior_c;
     p.morph_flags = t->morph_flags; p.morph_b = t->morph_b; p.morph_r = t->morph_r; p.morph_p = t->morph_p;
     p.morph_center = t->morph_center;
+    p.sp_tables = dc->d_tables;
+    { const char *e = getenv("MCMCHIP_NO_SOFTPLUS_TABLE"); p.no_table = e && e[0] == '1'; }
     p.nchain = nchain; p.nbatch = a->nbatch; p.blen = a->blen; p.nspac = a->nspac;
     p.scale_kind = a->scale_kind; p.scale = scale.as<double>();
     p.nout = nout; p.sq_from = sq_from; p.out_map = outmap.as<int>();

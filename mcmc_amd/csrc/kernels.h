@@ -13,6 +13,8 @@ struct MetropDev {
     int morph_flags;          // morph.metrop: the chain runs on the morphed state (R/morph.R:121-181)
     double morph_b, morph_r, morph_p;
     const double *morph_center;
+    const struct SoftplusTables *sp_tables;   // softplus tables in HBM (stream path: staged in LDS when they fit)
+    int no_table;             // 1: library exp/log1p even where the table would fit (MCMCHIP_NO_SOFTPLUS_TABLE=1, tests)
     // run shape
     long nchain;
     int nbatch, blen, nspac;

@@ -24,6 +24,7 @@
 struct StreamLayout {
     int x_in_lds;        // X and y staged in LDS
     int per_chain;       // doubles of LDS per chain: x, y, z, buf
+    int tab_in_lds;      // logistic posterior: the softplus table (softplus.h, 130 KB) sits at the start of LDS
     size_t lds_bytes;
 };
 
@@ -36,10 +37,13 @@ struct StreamLayout {
         __builtin_amdgcn_wave_barrier();                         \
     } while (0)
 
-template <int G>
+// KSEL >= 0 fixes the descriptor kind at compile time (the logistic posterior gets its own instantiation: with every
+// kind's density inlined behind one switch the register allocation of the generic kernel spills scalars and vectors
+// inside the iteration loop); KSEL = -1 is the generic kernel.
+template <int G, int KSEL>
 __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamLayout lay)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(32))) double lds[];
     constexpr int CPB = 256 / G;
     const int d = p.d, nout = p.nout;
     const int slot = threadIdx.x / G, g = threadIdx.x % G;
@@ -48,12 +52,17 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
     if (!live) chain = p.nchain - 1;   // keep the lanes in lockstep (barriers), suppress the stores
 
     TargetView tv;
-    tv.kind = p.kind; tv.d = d; tv.n = p.n; tv.par = p.par; tv.prior_c = p.prior_c;
-    tv.morph_flags = p.morph_flags; tv.morph_b = p.morph_b; tv.morph_r = p.morph_r; tv.morph_p = p.morph_p;
+    tv.kind = KSEL >= 0 ? KSEL : p.kind; tv.d = d; tv.n = p.n; tv.par = p.par; tv.prior_c = p.prior_c;
+    tv.morph_flags = KSEL >= 0 ? 0 : p.morph_flags; tv.morph_b = p.morph_b; tv.morph_r = p.morph_r; tv.morph_p = p.morph_p;
     tv.morph_center = p.morph_center;
     double *base = lds;
+    if (lay.tab_in_lds) {              // 32-byte aligned at offset 0; published by the barrier below
+        for (int i = threadIdx.x; i < SP_TAB_DOUBLES; i += 256) lds[i] = p.sp_tables->e[i];
+        tv.sp_shift = softplus_lds_shift(lds);
+        base = lds + SP_TAB_DOUBLES;
+    }
     if (lay.x_in_lds) {
-        double *xs = lds, *ys = lds + p.n * d;
+        double *xs = base, *ys = base + p.n * d;
         for (long i = threadIdx.x; i < p.n * d; i += 256) xs[i] = p.x[i];
         for (long i = threadIdx.x; i < p.n; i += 256) ys[i] = p.y[i];
         tv.x = xs; tv.y = ys;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void metrop_stream_kernel(MetropDev p, StreamL
             }
             // ---- outfun + batch accumulation, once per blen step (metrop.c:273-275)
             const double *S = X;
-            if (p.morph_flags) {                        // morph$outfun: g(inverse(state)), morph.R:95-106
+            if (KSEL < 0 && p.morph_flags) {            // morph$outfun: g(inverse(state)), morph.R:95-106
                 morph_inverse_group<G>(tv, X, W, g);
                 S = W;
             }
@@ -199,10 +208,24 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
     int G = pick_group(work, p.nchain);
     StreamLayout lay;
     lay.per_chain = 3 * d + p.nout + (p.morph_flags ? d : 0);
-    const size_t budget = 64 * 1024;
+    // The logistic posterior spends its time in log1p(exp(-|eta|)), ~130 fp64 instructions from the library; with the
+    // 130 KB softplus table of the MFMA path staged in LDS it is ~15 (C2: 72 -> ms).  The table
+    // takes most of the LDS (one workgroup per CU), which the 5-9x shorter density more than pays for.
+    const size_t tab_bytes = (size_t)SP_TAB_DOUBLES * 8;
+    const bool want_tab = p.kind == MCMCHIP_T_LOGISTIC && p.sp_tables != nullptr && !p.no_table;
+    const size_t lds_max = 160 * 1024;
+    size_t budget = 64 * 1024;
     size_t xbytes = (p.x ? (size_t)(p.n * d + p.n) * 8 : 0);
+    lay.tab_in_lds = 0;
     for (;;) {
         size_t chains = (size_t)(256 / G) * lay.per_chain * 8;
+        if (want_tab && tab_bytes + chains <= lds_max) {
+            lay.tab_in_lds = 1;
+            lay.x_in_lds = (xbytes > 0 && tab_bytes + xbytes + chains <= lds_max);
+            lay.lds_bytes = tab_bytes + chains + (lay.x_in_lds ? xbytes : 0);
+            budget = lds_max;
+            break;
+        }
         if (chains <= budget / 2 || G == 64) {
             lay.x_in_lds = (xbytes > 0 && xbytes + chains <= budget);
             lay.lds_bytes = chains + (lay.x_in_lds ? xbytes : 0);
@@ -214,12 +237,22 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
         return set_error(MCMCHIP_EINVAL, "state dimension %d too large for the stream path", d);
     const int cpb = 256 / G;
     dim3 grid((unsigned)((p.nchain + cpb - 1) / cpb)), block(256);
+    const bool special = p.kind == MCMCHIP_T_LOGISTIC && !p.morph_flags;      // the specialised instantiation
+#define STREAM_LAUNCH(GG) \
+    do { \
+        auto kern = special ? metrop_stream_kernel<GG, MCMCHIP_T_LOGISTIC> : metrop_stream_kernel<GG, -1>; \
+        if (lay.lds_bytes > 48 * 1024) \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lay.lds_bytes)); \
+        hipLaunchKernelGGL(kern, grid, block, lay.lds_bytes, s, p, lay); \
+    } while (0)
     switch (G) {
-    case 1: hipLaunchKernelGGL(metrop_stream_kernel<1>, grid, block, lay.lds_bytes, s, p, lay); break;
-    case 4: hipLaunchKernelGGL(metrop_stream_kernel<4>, grid, block, lay.lds_bytes, s, p, lay); break;
-    case 16: hipLaunchKernelGGL(metrop_stream_kernel<16>, grid, block, lay.lds_bytes, s, p, lay); break;
-    default: hipLaunchKernelGGL(metrop_stream_kernel<64>, grid, block, lay.lds_bytes, s, p, lay); break;
+    case 1: STREAM_LAUNCH(1); break;
+    case 4: STREAM_LAUNCH(4); break;
+    case 16: STREAM_LAUNCH(16); break;
+    default: STREAM_LAUNCH(64); break;
     }
+#undef STREAM_LAUNCH
     HIP_TRY(hipGetLastError());
     return MCMCHIP_OK;
 }

@@ -138,6 +138,22 @@ __device__ __forceinline__ double softplus_half_abs_lds(double eta, double shift
     softplus_lds_load(softplus_lds_addr(eta, shiftb), t);
     return softplus_lds_eval(eta, t);
 }
+// the same without inline asm (asm is convergent in device code, which keeps the compiler from unrolling a loop with a
+// run-time trip count around it): for loops over observations outside the MFMA kernel, where an instruction more or
+// less does not matter
+__device__ __forceinline__ double softplus_half_abs_lds_plain(double eta, double shiftb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double ac = fmin(__builtin_fabs(eta), (double)SP_ACLAMP);      // NaN -> the clamp -> last cell, as v_min_f64
+    const double jd = sp_fma(ac, SP_SCALE, shiftb);
+    const uint32_t addr = (uint32_t)__double2loint(jd) << 5;
+    SoftplusRec t;
+    softplus_lds_load(addr, t);
+    return softplus_lds_eval(eta, t);
+#else
+    return 0.0;
+#endif
+}
 #endif
 
 // host-side table construction in long double.  L^(k)(a) is a polynomial p_k in s = e^-a / (1 + e^-a):

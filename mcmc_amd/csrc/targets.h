@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/mcmchip.h"
+#include "softplus.h"
 
 struct TargetView {
     int kind, d;
@@ -19,12 +20,30 @@ struct TargetView {
     int morph_flags;
     double morph_b, morph_r, morph_p;
     const double *morph_center;
+    double sp_shift = 0.0;   // != 0: the softplus table is staged in LDS (softplus_lds_shift); 0: library exp/log1p
 };
 
+// lane i <- lane (i + n) mod 16 of its row of 16 (DPP row_ror) / a quad permutation: ~8 cycles instead of the ~120 of
+// a ds_bpermute round trip
+template <int CTRL> __device__ __forceinline__ double dpp_mov64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// xor butterfly, strides G/2 .. 1.  Within a row of 16 lanes the strides 8, 4, 2, 1 (in that order) are done with
+// row rotations instead: after the stride-s step the partial sums have period s along the row, so lane i and its
+// rotation partner hold the two halves of the same coset, exactly the pair the xor butterfly adds (commutative):
+// bit-identical totals on every lane, as before.
 template <int G> __device__ __forceinline__ double group_sum(double v)
 {
 #pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, G);
+    for (int m = G / 2; m >= 16; m >>= 1) v += __shfl_xor(v, m, G);
+    if (G >= 16) v += dpp_mov64<0x128>(v);      // row_ror:8
+    if (G >= 16) v += dpp_mov64<0x124>(v);      // row_ror:4
+    if (G >= 4) v += dpp_mov64<0x4E>(v);        // quad_perm [2,3,0,1]: xor 2
+    if (G >= 4) v += dpp_mov64<0xB1>(v);        // quad_perm [1,0,3,2]: xor 1
     return v;
 }
 
@@ -68,8 +87,44 @@ template <int G> __device__ double normmix_group(const double *par, int d, const
     return m + log(acc);
 }
 
+// log-likelihood terms of the logistic posterior (vignettes/demo.Rnw:59-65) over this lane's observations.
+// eta is accumulated j-ascending with separately rounded multiply and add, like the reference's x %*% beta.
+// D > 0: dimension known at compile time (state in registers, j loop unrolled); D = 0: run-time d.
+// l1 = log1p(exp(-|eta|)) comes from the library, or -- TAB: table staged in LDS, a kernel-uniform choice -- as
+// M(eta) - |eta|/2 with the <= 2 ulp table expansion of M = |eta|/2 + l1 (softplus.h): the absolute error is that
+// of rounding eta itself; fmax keeps l1 = 0 where M and |eta|/2 are both +Inf.
+template <int G, int D, bool TAB>
+__device__ __forceinline__ void logistic_terms(const TargetView &t, const double *v, int g, double &lp, double &lq)
+{
+    const int d = D > 0 ? D : t.d;
+    double vr[D > 0 ? D : 1];
+    if (D > 0) {
+#pragma unroll
+        for (int j = 0; j < D; j++) vr[j] = v[j];
+    }
+#pragma unroll 4
+    for (long i = g; i < t.n; i += G) {
+        const double *xi = t.x + (size_t)i * d;
+        double eta = 0.0;
+        if (D > 0) {
+#pragma unroll
+            for (int j = 0; j < D; j++) eta = add_nofma(eta, mul_nofma(xi[j], vr[j]));
+        } else {
+#pragma unroll 4
+            for (int j = 0; j < d; j++) eta = add_nofma(eta, mul_nofma(xi[j], v[j]));
+        }
+        // branch-free form of the reference's ifelse (vignettes/demo.Rnw:61-62): same operations per branch
+        const double l1 = TAB ? fmax(softplus_half_abs_lds_plain(eta, t.sp_shift) - 0.5 * fabs(eta), 0.0)
+                              : log1p(exp(-fabs(eta)));
+        if (t.y[i] == 1.0) lp += (eta < 0) ? eta - l1 : -l1;
+        else lq += (eta < 0) ? -l1 : -eta - l1;
+    }
+}
+
 // metrop targets; v = state[d]
-template <int G> __device__ double lud_group(const TargetView &t, const double *v, int g)
+// forced inline: as a real call the TargetView travels through scratch memory and every field, X and y included, is
+// re-read from there through flat loads (measured: the C2 iteration spent 8 500 of its 12 000 cycles in this call)
+template <int G> __device__ __forceinline__ double lud_group(const TargetView &t, const double *v, int g)
 {
     const int d = t.d;
     switch (t.kind) {
@@ -77,15 +132,20 @@ template <int G> __device__ double lud_group(const TargetView &t, const double *
         // vignettes/demo.Rnw:59-65; eta accumulated j-ascending with separately rounded
         // multiply and add, like the reference's x %*% beta
         double lp = 0.0, lq = 0.0, ss = 0.0;
-#pragma unroll 4
-        for (long i = g; i < t.n; i += G) {
-            const double *xi = t.x + (size_t)i * d;
-            double eta = 0.0;
-            for (int j = 0; j < d; j++) eta = add_nofma(eta, mul_nofma(xi[j], v[j]));
-            // branch-free form of the reference's ifelse (vignettes/demo.Rnw:61-62): same operations per branch
-            const double l1 = log1p(exp(-fabs(eta)));
-            if (t.y[i] == 1.0) lp += (eta < 0) ? eta - l1 : -l1;
-            else lq += (eta < 0) ? -l1 : -eta - l1;
+        // the state goes to registers and the j loop is unrolled for the usual small dimensions (with a run-time d
+        // every term of every eta waited for its own pair of LDS reads: 70 % of a C2 iteration)
+        const bool tab = t.sp_shift != 0.0;
+        switch (d) {
+#define LOGIT_CASE(DD) \
+        case DD: \
+            if (tab) logistic_terms<G, DD, true>(t, v, g, lp, lq); \
+            else logistic_terms<G, DD, false>(t, v, g, lp, lq); \
+            break;
+        LOGIT_CASE(1) LOGIT_CASE(2) LOGIT_CASE(3) LOGIT_CASE(4) LOGIT_CASE(5) LOGIT_CASE(6) LOGIT_CASE(7) LOGIT_CASE(8)
+#undef LOGIT_CASE
+        default:
+            if (tab) logistic_terms<G, 0, true>(t, v, g, lp, lq);
+            else logistic_terms<G, 0, false>(t, v, g, lp, lq);
         }
         for (int j = g; j < d; j += G) ss += v[j] * v[j];
         lp = group_sum<G>(lp);
@@ -208,7 +268,7 @@ __device__ inline double morph_dfinv(const TargetView &t, double x)
 
 // w = inverse(y) = f.inv(|y|) y/|y| + center (morph.R:5-14,162), written by the chain's G lanes into w (LDS,
 // same wavefront: no barrier needed); returns |y|
-template <int G> __device__ double morph_inverse_group(const TargetView &t, const double *y, double *w, int g)
+template <int G> __device__ __forceinline__ double morph_inverse_group(const TargetView &t, const double *y, double *w, int g)
 {
     const int d = t.d;
     const bool shaped = t.morph_flags & (MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO);
@@ -231,7 +291,7 @@ template <int G> __device__ double morph_inverse_group(const TargetView &t, cons
 
 // what logh() sees under morph.metrop (morph.R:166-179): lud(inverse(y)) + log.jacobian(y); -Inf, NaN and +Inf of
 // the descriptor pass through unchanged for the caller's checks
-template <int G> __device__ double lud_morphed_group(const TargetView &t, const double *y, double *w, int g)
+template <int G> __device__ __forceinline__ double lud_morphed_group(const TargetView &t, const double *y, double *w, int g)
 {
     if (!t.morph_flags) return lud_group<G>(t, y, g);
     const double nrm = morph_inverse_group<G>(t, y, w, g);
