@@ -133,7 +133,7 @@ template <int G> __device__ __forceinline__ double lud_group(const TargetView &t
         // multiply and add, like the reference's x %*% beta
         double lp = 0.0, lq = 0.0, ss = 0.0;
         // the state goes to registers and the j loop is unrolled for the usual small dimensions (with a run-time d
-        // every term of every eta waited for its own pair of LDS reads: 70 % of a C2 iteration)
+        // every term of every eta waits for its own pair of loads)
         const bool tab = t.sp_shift != 0.0;
         switch (d) {
 #define LOGIT_CASE(DD) \
