@@ -10,7 +10,7 @@
 #include "softplus.h"
 
 #define MCMCHIP_MAX_DEVICES 16
-#define MCMCHIP_MFMA_MAXD 64
+#define MCMCHIP_MFMA_MAXD 128
 
 struct DeviceCtx {
     bool inited = false;

@@ -34,7 +34,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define MFMA_NW 8          // wavefronts per workgroup (2 per SIMD: a second wave fills MFMA dependency gaps)
 #define MFMA_NC 2          // 16-chain tiles per wavefront -> 256 chains per workgroup
 // observation tiles per LDS chunk: 16 KB per buffer whatever d is
-static inline int mfma_tc(int ks) { return ks <= 2 ? 16 : (ks <= 4 ? 8 : (ks <= 8 ? 4 : 2)); }
+static inline int mfma_tc(int ks) { return ks <= 2 ? 16 : (ks <= 4 ? 8 : (ks <= 8 ? 4 : (ks <= 16 ? 2 : 1))); }
 
 // ---------------------------------------------------------------------------------------------
 __global__ void tile_x_kernel(const double *__restrict__ x, const double *__restrict__ y, long n, int d,
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void tile_colsum_kernel(const double *__restri
 
 int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 {
-    t->dpad = ((t->d + 7) / 8) * 8;
+    t->dpad = t->d <= 64 ? ((t->d + 7) / 8) * 8 : ((t->d + 15) / 16) * 16;   // d > 64: k-steps in {20, 24, 28, 32}
     if (t->dpad < 8) t->dpad = 8;
     t->ksteps = t->dpad / 4;
     long tiles = (t->n + 15) / 16;
@@ -207,27 +207,54 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     };
 
     double4_t acc2[2][NC];        // ping-pong accumulators: tile tt uses acc2[tt & 1]
-    static_assert(TC % 2 == 0, "the last tile of a chunk must leave its accumulators in acc2[1]");
-    for (long ch = 0; ch < nchunks; ch++) {
-        const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
-        const double *xs = sX + buf * CHUNK + lane;
-        if (ch == 0) {
-            mfma_tile(xs, 0, acc2[0]);
-        } else {
-            mfma_tile(xs, 0, acc2[0]);
-            epilogue(acc2[1]);                 // the last tile of the previous chunk
+    static_assert(TC == 1 || TC % 2 == 0, "the last tile of a chunk must leave its accumulators in acc2[1]");
+    if (TC == 1) {
+        // 64 < d <= 128: one 16-observation tile (KS up to 32 k-steps) fills a 16 KB buffer, so the chunk loop is
+        // unrolled by two to keep the accumulator ping-pong static: even chunks use buffer 0 / acc2[0], odd ones 1
+        int last = 1;
+        for (long ch = 0; ch < nchunks; ch += 2) {
+            if (ch + 1 < nchunks) stage(ch + 1, 1);
+            mfma_tile(sX + lane, 0, acc2[0]);
+            if (ch > 0) {
+                epilogue(acc2[1]);
+                interleave();
+            }
+            __syncthreads();
+            last = 0;
+            if (ch + 1 >= nchunks) break;
+            if (ch + 2 < nchunks) stage(ch + 2, 0);
+            mfma_tile(sX + CHUNK + lane, 0, acc2[1]);
+            epilogue(acc2[0]);
             interleave();
+            __syncthreads();
+            last = 1;
         }
+        if (nchunks > 0) {
+            if (last == 0) epilogue(acc2[0]);
+            else epilogue(acc2[1]);
+        }
+    } else {
+        for (long ch = 0; ch < nchunks; ch++) {
+            const int buf = (int)(ch & 1);
+            if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+            const double *xs = sX + buf * CHUNK + lane;
+            if (ch == 0) {
+                mfma_tile(xs, 0, acc2[0]);
+            } else {
+                mfma_tile(xs, 0, acc2[0]);
+                epilogue(acc2[1]);                 // the last tile of the previous chunk
+                interleave();
+            }
 #pragma unroll
-        for (int tt = 1; tt < TC; tt++) {
-            mfma_tile(xs, tt, acc2[tt & 1]);
-            epilogue(acc2[(tt + 1) & 1]);
-            interleave();
+            for (int tt = 1; tt < TC; tt++) {
+                mfma_tile(xs, tt, acc2[tt & 1]);
+                epilogue(acc2[(tt + 1) & 1]);
+                interleave();
+            }
+            __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
         }
-        __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
+        if (nchunks > 0) epilogue(acc2[1]);
     }
-    if (nchunks > 0) epilogue(acc2[1]);
 
     // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
 #pragma unroll
@@ -444,6 +471,10 @@ static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const dou
     case 12: launch_ld<12, 2>(pl, t, prop, partial, dc); break;
     case 14: launch_ld<14, 2>(pl, t, prop, partial, dc); break;
     case 16: launch_ld<16, 2>(pl, t, prop, partial, dc); break;
+    case 20: launch_ld<20, 1>(pl, t, prop, partial, dc); break;
+    case 24: launch_ld<24, 1>(pl, t, prop, partial, dc); break;
+    case 28: launch_ld<28, 1>(pl, t, prop, partial, dc); break;
+    case 32: launch_ld<32, 1>(pl, t, prop, partial, dc); break;
     default: return set_error(MCMCHIP_EINVAL, "MFMA path supports d <= %d", MCMCHIP_MFMA_MAXD);
     }
     HIP_TRY(hipGetLastError());

@@ -231,7 +231,8 @@ def _synthetic(n, d, seed=42):
     return X, y, beta
 
 
-@pytest.mark.parametrize("n,d,C", [(20000, 64, 256), (5003, 5, 100), (8192, 20, 300), (4099, 33, 64)])
+@pytest.mark.parametrize("n,d,C", [(20000, 64, 256), (5003, 5, 100), (8192, 20, 300), (4099, 33, 64),
+                                   (6007, 65, 70), (4099, 100, 64), (8192, 128, 300), (33, 96, 5)])   # d > 64: one tile per chunk
 def test_logdens_mfma_vs_oracle(api, oracle_mod, n, d, C):
     X, y, beta = _synthetic(n, d, seed=n)
     states = beta + 0.3 * np.random.default_rng(1).standard_normal((C, d))
@@ -244,14 +245,16 @@ def test_logdens_mfma_vs_oracle(api, oracle_mod, n, d, C):
 
 
 @pytest.mark.parametrize("scale_kind", ["scalar", "matrix"])
-def test_metrop_mfma_injected_vs_oracle(api, oracle_mod, scale_kind):
-    n, d, C, nbatch, blen, nspac = 8192, 16, 128, 6, 3, 2
+@pytest.mark.parametrize("d", [16, 80])
+def test_metrop_mfma_injected_vs_oracle(api, oracle_mod, scale_kind, d):
+    n, C, nbatch, blen, nspac = 8192, 128, 6, 3, 2
     niter = nbatch * blen * nspac
     X, y, beta = _synthetic(n, d)
     rng = np.random.default_rng(2)
     init = beta + 0.01 * rng.standard_normal((C, d))
     z, u = rng.standard_normal((C, niter, d)), rng.random((C, niter))
-    scale = 0.02 if scale_kind == "scalar" else 0.02 * np.linalg.cholesky(np.eye(d) + 0.3)
+    s0 = 0.02 if d == 16 else 0.008
+    scale = s0 if scale_kind == "scalar" else s0 * np.linalg.cholesky(np.eye(d) + 0.3)
     ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), init, nbatch, blen, nspac,
                             scale=scale, z=z, u=u, outfun="moments2", nthreads=16)
     o = api.metrop(api.logistic_target(X, y), init, nbatch, blen, nspac, scale=scale, z=z, u=u, outfun="moments2",
