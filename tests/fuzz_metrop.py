@@ -15,7 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ONLY = int(sys.argv[3]) if len(sys.argv) > 3 else None     # [only this configuration index], with details
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
-    d = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64]))
+    d = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 96, 128]))
     C = int(rng.choice([1, 3, 16, 65, 200]))
     nbatch, blen, nspac = int(rng.integers(1, 12)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
     niter = nbatch * blen * nspac
