@@ -21,6 +21,7 @@ struct TargetView {
     double morph_b, morph_r, morph_p;
     const double *morph_center;
     double sp_shift = 0.0;   // != 0: the softplus table is staged in LDS (softplus_lds_shift); 0: library exp/log1p
+    int xy_in_lds = 0;       // x and y point into LDS: read them with ds_read, not through the flat aperture
 };
 
 // lane i <- lane (i + n) mod 16 of its row of 16 (DPP row_ror) / a quad permutation: ~8 cycles instead of the ~120 of
@@ -93,9 +94,13 @@ template <int G> __device__ double normmix_group(const double *par, int d, const
 // l1 = log1p(exp(-|eta|)) comes from the library, or -- TAB: table staged in LDS, a kernel-uniform choice -- as
 // M(eta) - |eta|/2 with the <= 2 ulp table expansion of M = |eta|/2 + l1 (softplus.h): the absolute error is that
 // of rounding eta itself; fmax keeps l1 = 0 where M and |eta|/2 are both +Inf.
-template <int G, int D, bool TAB>
+template <int G, int D, bool TAB, bool XL>
 __device__ __forceinline__ void logistic_terms(const TargetView &t, const double *v, int g, double &lp, double &lq)
 {
+    // XL: X and y live in LDS.  A generic pointer makes every read a FLAT instruction, whose LDS aperture path is far
+    // slower than ds_read; the cast hands the compiler the address space.
+    typedef __attribute__((address_space(3))) const double lds_cd;
+    lds_cd *xl = XL ? (lds_cd *)t.x : nullptr, *yl = XL ? (lds_cd *)t.y : nullptr;
     const int d = D > 0 ? D : t.d;
     double vr[D > 0 ? D : 1];
     if (D > 0) {
@@ -105,18 +110,19 @@ __device__ __forceinline__ void logistic_terms(const TargetView &t, const double
 #pragma unroll 4
     for (long i = g; i < t.n; i += G) {
         const double *xi = t.x + (size_t)i * d;
+        lds_cd *xli = xl + (size_t)i * d;
         double eta = 0.0;
         if (D > 0) {
 #pragma unroll
-            for (int j = 0; j < D; j++) eta = add_nofma(eta, mul_nofma(xi[j], vr[j]));
+            for (int j = 0; j < D; j++) eta = add_nofma(eta, mul_nofma(XL ? xli[j] : xi[j], vr[j]));
         } else {
 #pragma unroll 4
-            for (int j = 0; j < d; j++) eta = add_nofma(eta, mul_nofma(xi[j], v[j]));
+            for (int j = 0; j < d; j++) eta = add_nofma(eta, mul_nofma(XL ? xli[j] : xi[j], v[j]));
         }
         // branch-free form of the reference's ifelse (vignettes/demo.Rnw:61-62): same operations per branch
         const double l1 = TAB ? fmax(softplus_half_abs_lds_plain(eta, t.sp_shift) - 0.5 * fabs(eta), 0.0)
                               : log1p(exp(-fabs(eta)));
-        if (t.y[i] == 1.0) lp += (eta < 0) ? eta - l1 : -l1;
+        if ((XL ? yl[i] : t.y[i]) == 1.0) lp += (eta < 0) ? eta - l1 : -l1;
         else lq += (eta < 0) ? -l1 : -eta - l1;
     }
 }
@@ -138,14 +144,16 @@ template <int G> __device__ __forceinline__ double lud_group(const TargetView &t
         switch (d) {
 #define LOGIT_CASE(DD) \
         case DD: \
-            if (tab) logistic_terms<G, DD, true>(t, v, g, lp, lq); \
-            else logistic_terms<G, DD, false>(t, v, g, lp, lq); \
+            if (tab && t.xy_in_lds) logistic_terms<G, DD, true, true>(t, v, g, lp, lq); \
+            else if (tab) logistic_terms<G, DD, true, false>(t, v, g, lp, lq); \
+            else logistic_terms<G, DD, false, false>(t, v, g, lp, lq); \
             break;
         LOGIT_CASE(1) LOGIT_CASE(2) LOGIT_CASE(3) LOGIT_CASE(4) LOGIT_CASE(5) LOGIT_CASE(6) LOGIT_CASE(7) LOGIT_CASE(8)
 #undef LOGIT_CASE
         default:
-            if (tab) logistic_terms<G, 0, true>(t, v, g, lp, lq);
-            else logistic_terms<G, 0, false>(t, v, g, lp, lq);
+            if (tab && t.xy_in_lds) logistic_terms<G, 0, true, true>(t, v, g, lp, lq);
+            else if (tab) logistic_terms<G, 0, true, false>(t, v, g, lp, lq);
+            else logistic_terms<G, 0, false, false>(t, v, g, lp, lq);
         }
         for (int j = g; j < d; j += G) ss += v[j] * v[j];
         lp = group_sum<G>(lp);
