@@ -63,14 +63,16 @@ template <int G> __device__ __forceinline__ int group_and(int v)
 }
 
 // isotropic finite normal mixture, par = K, then K x {a_k, b_k, mu_k[d]}
-template <int G> __device__ double normmix_group(const double *par, int d, const double *v, int g)
+// PT: const double * (global or generic) or an address-space-3 pointer when the parameter block is staged in LDS
+// (a generic pointer into LDS turns every read into a FLAT load, far slower than ds_read)
+template <int G, typename PT = const double *> __device__ double normmix_group(PT par, int d, const double *v, int g)
 {
     int K = (int)par[0];
-    const double *rec = par + 1;
+    PT rec = par + 1;
     // pass 1: max of the exponents, pass 2: sum of exp (components strided over lanes)
     double m = -INFINITY;
     for (int k = g; k < K; k += G) {
-        const double *r = rec + (size_t)k * (2 + d);
+        PT r = rec + (size_t)k * (2 + d);
         double s = 0.0;
         for (int j = 0; j < d; j++) { double t = v[j] - r[2 + j]; s += t * t; }
         m = fmax(m, r[0] - r[1] * s);
@@ -79,7 +81,7 @@ template <int G> __device__ double normmix_group(const double *par, int d, const
     if (m == -INFINITY) return -INFINITY;
     double acc = 0.0;
     for (int k = g; k < K; k += G) {
-        const double *r = rec + (size_t)k * (2 + d);
+        PT r = rec + (size_t)k * (2 + d);
         double s = 0.0;
         for (int j = 0; j < d; j++) { double t = v[j] - r[2 + j]; s += t * t; }
         acc += exp(r[0] - r[1] * s - m);
@@ -341,7 +343,8 @@ __device__ double lud_models_group(const double *par, int p, const double *x, co
 
 // temper targets; state = (i, theta[p]) with 1-based component i.  Small p: every lane of the
 // caller evaluates the whole thing (no cooperation), so this is a plain scalar function.
-__device__ inline double lud_temper(int kind, int p, const double *par, int ncomp, int i, const double *th)
+template <typename PT = const double *>
+__device__ inline double lud_temper(int kind, int p, PT par, int ncomp, int i, const double *th)
 {
     switch (kind) {
     case MCMCHIP_T_WITCH: {
@@ -361,7 +364,7 @@ __device__ inline double lud_temper(int kind, int p, const double *par, int ncom
     case MCMCHIP_T_TEMPERED_NORMMIX: {
         int k = (int)par[0];
         double beta = par[i];
-        return beta * normmix_group<1>(par + 1 + k, p, th, 0);
+        return beta * normmix_group<1, PT>(par + 1 + k, p, th, 0);
     }
     default:
         return NAN;

@@ -70,8 +70,12 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     // log density of (component comp, theta): called with wave-uniform arguments only.  The data-carrying
     // kind spreads its observations over the 64 lanes; the small closed-form kinds are scalar per lane.
     const bool coop = q.kind == MCMCHIP_T_LOGISTIC_MODELS;
+    typedef __attribute__((address_space(3))) const double lds_cd;
+    const bool par_lds = lay.npar_lds > 0;
     auto LUD = [&](int comp, const double *th) -> double {
         if (coop) return lud_models_group<64>(gpar, p, q.x, q.y, q.n, q.prior_c, comp, th, lane);
+        // parameters staged in LDS are read with ds_read (through a generic pointer they would be FLAT loads)
+        if (par_lds) return lud_temper<lds_cd *>(q.kind, p, (lds_cd *)gpar, k, comp, th);
         return lud_temper(q.kind, p, gpar, k, comp, th);
     };
 
@@ -524,8 +528,12 @@ __global__ __launch_bounds__(192) void temper_run_kernel(TemperDev q, TemperRunL
     unsigned axn = 0, axd = 0;
     double wb = 0.0, win = 0.0, wco = 0.0;
     if (WITCH) { wb = q.par[c]; win = q.par[k + c]; wco = q.par[2 * k + c]; }
+    typedef __attribute__((address_space(3))) const double lds_cd;
+    const bool par_lds = lay.npar_lds > 0;
     auto LUD_OWN = [&](const double *th) -> double {                  // log density of (component c, th)
         if (WITCH) return witch_value<P>(wb, win, wco, th);
+        // parameters staged in LDS are read with ds_read (through a generic pointer they would be FLAT loads)
+        if (par_lds) return lud_temper<lds_cd *>(KIND, P, (lds_cd *)gpar, k, c + 1, th);
         return lud_temper(KIND, P, gpar, k, c + 1, th);
     };
     double L = LUD_OWN(x);                                            // temper.c:98-119
