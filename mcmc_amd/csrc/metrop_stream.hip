@@ -18,6 +18,7 @@
 // (mul_nofma/add_nofma: no FMA contraction, as in the reference's x86-64 build); full-matrix
 // scale accumulates column by column in i order (metrop.c:391-399).
 #include "metrop_stream_impl.h"
+#include <stdlib.h>
 
 static int pick_group(long work, long nchain)
 {
@@ -37,6 +38,10 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
     else if (p.kind == MCMCHIP_T_NORMMIX) work = 8;
     else if (p.morph_flags && d <= 16) work = 1;   // small morphed targets: one lane per chain keeps the norm's summation order
     int G = pick_group(work, p.nchain);
+    if (const char *e = getenv("MCMCHIP_STREAM_G")) {       // experiments: force the lanes per chain (1, 4, 16, 64)
+        const int f = atoi(e);
+        if (f == 1 || f == 4 || f == 16 || f == 64) G = f;
+    }
     StreamLayout lay;
     const int blocks_it = (d + 1) / 2 + 1;                    // Philox blocks per iteration: normals + the uniform
     auto ahead = [&](int GG) { return p.rng_mode == MCMCHIP_RNG_INJECTED ? 0 : (GG / blocks_it > 1 ? (GG / blocks_it > 8 ? 8 : GG / blocks_it) : 1); };
