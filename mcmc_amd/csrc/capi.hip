@@ -235,6 +235,15 @@ static int check_flag(DeviceCtx *dc, bool temper)
     return set_error(MCMCHIP_EDOMAIN, "Can't happen: log hastings ratio +Inf or NaN\n");
 }
 
+// AUTO rule between the two metrop paths, from tools/path_crossover.py (profiles/r1_path_crossover.txt): the MFMA path
+// pays two launches and a 130 KB table load per workgroup and iteration, so it needs enough contraction work
+// (n x d) or enough chains; below that the persistent stream kernel is faster.
+static bool mfma_pays(const mcmchip_target *t, long nchain)
+{
+    if (nchain < 64 || t->n < 1024) return false;
+    return (long)t->n * t->d >= 65536 || (t->n >= 4096 && nchain >= 32768);
+}
+
 int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchain, int path,
                     int device_ptrs, double *out)
 {
@@ -248,7 +257,7 @@ int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchai
     HIP_TRY(in.set(states, (size_t)nchain * w * 8, device_ptrs, dc->stream));
     HIP_TRY(ob.set(out, (size_t)nchain * 8, device_ptrs));
     if (path == MCMCHIP_PATH_MFMA && t->morph_flags) return set_error(MCMCHIP_EINVAL, "the MFMA path does not take a morphed descriptor");
-    bool mfma = (path == MCMCHIP_PATH_MFMA) || (path == MCMCHIP_PATH_AUTO && t->xt && !t->morph_flags && t->n >= 4096 && nchain >= 64);
+    bool mfma = (path == MCMCHIP_PATH_MFMA) || (path == MCMCHIP_PATH_AUTO && t->xt && !t->morph_flags && mfma_pays(t, nchain));
     int rc;
     if (mfma) rc = launch_logdens_mfma(t, in.as<double>(), nchain, ob.as<double>(), dc);
     else rc = launch_logdens_stream(t, in.as<double>(), nchain, ob.as<double>(), dc->stream);
@@ -315,7 +324,7 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
     if (!o->accept || !o->batch || !o->final || !o->accept_batch) return set_error(MCMCHIP_EINVAL, "null output");
 
     bool mfma_ok = t->xt && !a->debug && !t->morph_flags;
-    bool mfma = (a->path == MCMCHIP_PATH_MFMA) || (a->path == MCMCHIP_PATH_AUTO && mfma_ok && t->n >= 4096 && nchain >= 64);
+    bool mfma = (a->path == MCMCHIP_PATH_MFMA) || (a->path == MCMCHIP_PATH_AUTO && mfma_ok && mfma_pays(t, nchain));
     if (mfma && !mfma_ok) return set_error(MCMCHIP_EINVAL, "MFMA path needs a logistic descriptor with d <= %d and debug = FALSE", MCMCHIP_MFMA_MAXD);
 
     hipStream_t s = dc->stream;
