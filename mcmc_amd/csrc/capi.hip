@@ -241,7 +241,7 @@ static int check_flag(DeviceCtx *dc, bool temper)
 static bool mfma_pays(const mcmchip_target *t, long nchain)
 {
     if (nchain < 64 || t->n < 1024) return false;
-    return (long)t->n * t->d >= 65536 || (t->n >= 4096 && nchain >= 32768);
+    return (long)t->n * t->d >= 65536 || (t->n >= 4096 && nchain >= 4096);
 }
 
 int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchain, int path,

@@ -18,7 +18,12 @@ struct DeviceCtx {
     SoftplusTables *d_tables = nullptr;  // softplus tables in HBM
     int *d_flag = nullptr;               // error flag word shared by the kernels
     int num_cu = 256;
+    // scratch of the MFMA path (state / proposal / partial sums / accumulators), kept between calls: a call used to pay
+    // seven hipMalloc/hipFree pairs (~3 ms).  Grows on demand; released after a call when it exceeds MCMCHIP_WS_KEEP.
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
 };
+#define MCMCHIP_WS_KEEP ((size_t)2 << 30)
 
 // per-process state (one process per GPU in the multi-GPU launch, but any device may be selected)
 struct LibCtx {

@@ -436,11 +436,11 @@ static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
     long chunks = t->ntiles / tc;
     // one workgroup per CU (LDS-bound occupancy).  A grid that is a whole number of chip-fulls needs no
     // observation split; otherwise split the observations until the tail round is small, keeping
-    // >= 8 chunks per workgroup so the B-fragment preload amortises.
+    // >= 2 chunks per workgroup (with 8 a 4096 x 5 posterior over 4096 chains ran on 32 workgroups).
     long want = 1;
     if (pl.chain_blocks % num_cu != 0) {
         want = (4L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;
-        long maxsplit = chunks / 8 > 0 ? chunks / 8 : 1;
+        long maxsplit = chunks / 2 > 0 ? chunks / 2 : 1;     // >= 2 chunks per workgroup (table load and B preload cost a few us)
         if (want > maxsplit) want = maxsplit;
         if (want > 256) want = 256;
     }
@@ -481,6 +481,36 @@ static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const dou
     return MCMCHIP_OK;
 }
 
+// carve the MFMA path's scratch buffers out of the device's cached workspace (256-byte aligned pieces)
+struct Workspace {
+    DeviceCtx *dc;
+    size_t need = 0, off = 0;
+    std::vector<size_t> sizes;
+    explicit Workspace(DeviceCtx *d) : dc(d) {}
+    void want(size_t bytes) { sizes.push_back((bytes + 255) & ~(size_t)255); need += sizes.back(); }
+    int reserve()
+    {
+        if (need > dc->ws_bytes) {
+            if (dc->ws) (void)hipFree(dc->ws);
+            dc->ws = nullptr;
+            dc->ws_bytes = 0;
+            HIP_TRY(hipMalloc(&dc->ws, need));
+            dc->ws_bytes = need;
+        }
+        return MCMCHIP_OK;
+    }
+    size_t next = 0;
+    double *take() { double *p = (double *)((char *)dc->ws + off); off += sizes[next++]; return p; }
+    void done()          // after the stream has been synchronised
+    {
+        if (dc->ws_bytes > MCMCHIP_WS_KEEP) {
+            (void)hipFree(dc->ws);
+            dc->ws = nullptr;
+            dc->ws_bytes = 0;
+        }
+    }
+};
+
 int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
 {
     if (!t->xt) return set_error(MCMCHIP_EINVAL, "target has no MFMA tiles (not a logistic target)");
@@ -488,18 +518,21 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     hipStream_t s = dc->stream;
     MfmaPlan pl = make_plan(t, p.nchain, dc->num_cu);
     const long ldc = pl.ldc;
-    DevBuf state, prop, partial, cur, acc, acc_b, buf;
-    HIP_TRY(state.alloc((size_t)t->dpad * ldc * 8));
-    HIP_TRY(prop.alloc((size_t)t->dpad * ldc * 8));
-    HIP_TRY(partial.alloc((size_t)pl.nsplit * ldc * 8));
-    HIP_TRY(cur.alloc((size_t)ldc * 8));
-    HIP_TRY(acc.alloc((size_t)ldc * 8));
-    HIP_TRY(acc_b.alloc((size_t)ldc * 8));
-    HIP_TRY(buf.alloc((size_t)p.nout * ldc * 8));
+    Workspace ws(dc);
+    ws.want((size_t)t->dpad * ldc * 8);
+    ws.want((size_t)t->dpad * ldc * 8);
+    ws.want((size_t)pl.nsplit * ldc * 8);
+    ws.want((size_t)ldc * 8);
+    ws.want((size_t)ldc * 8);
+    ws.want((size_t)ldc * 8);
+    ws.want((size_t)(p.nout > 0 ? p.nout : 1) * ldc * 8);
+    if (int rc = ws.reserve()) return rc;
+    double *state = ws.take(), *prop = ws.take(), *partial = ws.take(), *cur = ws.take(), *acc = ws.take(),
+           *acc_b = ws.take(), *buf = ws.take();
 
     long total = (long)t->dpad * ldc;
     hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.initial,
-                       p.nchain, t->d, t->dpad, ldc, state.as<double>(), prop.as<double>());
+                       p.nchain, t->d, t->dpad, ldc, state, prop);
     HIP_TRY(hipGetLastError());
 
     UpdParams q;
@@ -512,10 +545,10 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     q.nout = p.nout; q.sq_from = p.sq_from; q.out_map = p.out_map;
     q.rng_mode = p.rng_mode; q.z = p.z; q.u = p.u;
     q.seed = p.seed; q.chain_offset = p.chain_offset; q.iter_offset = p.iter_offset;
-    q.partial = partial.as<double>();
+    q.partial = partial;
     q.colsum = t->colsum;
-    q.state = state.as<double>(); q.prop = prop.as<double>();
-    q.cur = cur.as<double>(); q.acc = acc.as<double>(); q.acc_b = acc_b.as<double>(); q.buf = buf.as<double>();
+    q.state = state; q.prop = prop;
+    q.cur = cur; q.acc = acc; q.acc_b = acc_b; q.buf = buf;
     q.batch = p.batch; q.accept_batch = p.accept_batch; q.accept = p.accept; q.final_ = p.final_;
     q.logdens_out = nullptr;
     q.flag = p.flag;
@@ -525,13 +558,14 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     timing_reset("logdens_mfma_kernel");
     for (long l = -1; l < niter; l++) {
         timing_begin(s);
-        int rc = launch_logdens(pl, t, prop.as<double>(), partial.as<double>(), dc);
+        int rc = launch_logdens(pl, t, prop, partial, dc);
         timing_end(s);
         if (rc) return rc;
         hipLaunchKernelGGL(metrop_update_kernel, ugrid, ublock, 0, s, q, l);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipStreamSynchronize(s));   // the scratch buffers above are freed at scope exit
+    HIP_TRY(hipStreamSynchronize(s));
+    ws.done();
     return MCMCHIP_OK;
 }
 
