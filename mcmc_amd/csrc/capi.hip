@@ -2,6 +2,7 @@
 // reference's error texts, staging of host buffers through HBM, path selection, error flags.
 #include "kernels.h"
 #include <math.h>
+#include <new>
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -61,6 +62,42 @@ void timing_end(hipStream_t s)
     if (L.ev_used >= EV_MAX || (int)L.ev_stop.size() <= L.ev_used) return;
     (void)hipEventRecord(L.ev_stop[L.ev_used], s);
     L.ev_used++;
+}
+
+// Inputs handed over as device pointers are validated on the device: the reference refuses a non-finite `initial`
+// (metrop.c:72-73, temper.c:129-131) or series (initseq.c:15) and, for serial tempering, a first element that is
+// not an integer in 1..k (temper.c:55-63) -- the kernels index LDS with it.
+#define VAL_NONFINITE 1
+#define VAL_NOTINT 2
+#define VAL_RANGE 4
+__global__ void validate_inputs_kernel(const double *__restrict__ v, long n, long stride, int k, int *__restrict__ flag)
+{
+    const long step = (long)gridDim.x * blockDim.x;
+    int bad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        const double x = v[i];
+        if (!isfinite(x)) bad |= VAL_NONFINITE;
+        else if (k > 0 && i % stride == 0) {
+            if (x != trunc(x)) bad |= VAL_NOTINT;
+            else if (x < 1.0 || x > (double)k) bad |= VAL_RANGE;
+        }
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
+// runs the validation kernel over v[0..n) and returns the VAL_* bits in *bits (k > 0: every stride-th element is a
+// serial-tempering component index)
+int device_validate(DeviceCtx *dc, const double *v, long n, long stride, int k, int *bits)
+{
+    int *f = dc->d_flag + 1;          // word 0 is the samplers' error flag
+    HIP_TRY(hipMemsetAsync(f, 0, sizeof(int), dc->stream));
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(validate_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, dc->stream, v, n, stride, k, f);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(bits, f, sizeof(int), hipMemcpyDeviceToHost, dc->stream));
+    HIP_TRY(hipStreamSynchronize(dc->stream));
+    return MCMCHIP_OK;
 }
 
 extern "C" {
@@ -138,10 +175,12 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
     if (desc->kind < MCMCHIP_T_LOGISTIC || desc->kind > MCMCHIP_T_BINOMIAL_LOGIT)
         return set_error(MCMCHIP_EINVAL, "unknown log density descriptor kind %d", desc->kind);
     if (desc->d <= 0) return set_error(MCMCHIP_EINVAL, "descriptor dimension must be positive");
-    mcmchip_target *t = new mcmchip_target();
+    mcmchip_target *t = new (std::nothrow) mcmchip_target();
+    if (!t) return set_error(MCMCHIP_EHIP, "out of host memory");
     t->kind = desc->kind; t->d = desc->d; t->prior_c = desc->prior_c; t->device = lib_ctx().device;
     hipMemcpyKind kind = desc_device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     int rc = MCMCHIP_OK;
+    try {
     do {
         if (is_logistic(desc->kind)) {
             if (desc->n <= 0 || !desc->x || !desc->y) { rc = set_error(MCMCHIP_EINVAL, "logistic descriptor needs x (n x d) and y (n)"); break; }
@@ -162,6 +201,25 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
                 if (hipMemcpy(t->host_par.data(), desc->par, (size_t)desc->npar * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of descriptor parameters failed"); break; }
             } else {
                 memcpy(t->host_par.data(), desc->par, (size_t)desc->npar * 8);
+            }
+            {
+                // length of the parameter block per kind (include/mcmchip.h): the kernels take K and k from par[0] and
+                // index the block with them, so a short block would be read out of bounds
+                const double *hp = t->host_par.data();
+                const long np_ = (long)desc->npar, dd = desc->d;
+                auto whole = [](double v, long lo) { return v >= (double)lo && v <= 1e9 && v == (double)(long)v; };
+                bool ok = true;
+                switch (desc->kind) {
+                case MCMCHIP_T_MVNORM: ok = np_ == dd + dd * dd; break;
+                case MCMCHIP_T_NORMMIX: ok = whole(hp[0], 1) && np_ == 1 + (long)hp[0] * (2 + dd); break;
+                case MCMCHIP_T_TEMPERED_NORMMIX:
+                    ok = whole(hp[0], 2) && np_ > 1 + (long)hp[0] && whole(hp[1 + (long)hp[0]], 1) &&
+                         np_ == 1 + (long)hp[0] + 1 + (long)hp[1 + (long)hp[0]] * (2 + dd);
+                    break;
+                case MCMCHIP_T_WITCH: ok = np_ >= 2; break;
+                default: break;       // SIMPLEX / STUDENT_T: one value (np_ >= 1 holds here); logistic kinds checked below
+                }
+                if (!ok) { rc = set_error(MCMCHIP_EINVAL, "descriptor kind %d: parameter block of %ld values does not match its layout", desc->kind, np_); break; }
             }
             if (desc->kind == MCMCHIP_T_WITCH) {
                 // the witch's hat takes only two values per component (tests/temp-par-witch.R:24-40): evaluate
@@ -206,6 +264,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
         }
         if (hipStreamSynchronize(dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "stream synchronize failed"); break; }
     } while (0);
+    } catch (const std::bad_alloc &) { rc = set_error(MCMCHIP_EHIP, "out of host memory"); }
     if (rc) { mcmchip_target_destroy(t); return rc; }
     *out = t;
     return MCMCHIP_OK;
@@ -238,6 +297,14 @@ static int check_flag(DeviceCtx *dc, bool temper)
 // AUTO rule between the two metrop paths, from tools/path_crossover.py (profiles/r1_path_crossover.txt): the MFMA path
 // pays two launches and a 130 KB table load per workgroup and iteration, so it needs enough contraction work
 // (n x d) or enough chains; below that the persistent stream kernel is faster.
+// a descriptor lives in the HBM of the device that was current when it was created
+static int check_target_device(const mcmchip_target *t)
+{
+    if (t->device != lib_ctx().device)
+        return set_error(MCMCHIP_EINVAL, "descriptor was created on device %d, the current device is %d", t->device, lib_ctx().device);
+    return MCMCHIP_OK;
+}
+
 static bool mfma_pays(const mcmchip_target *t, long nchain)
 {
     if (nchain < 64 || t->n < 1024) return false;
@@ -251,6 +318,7 @@ int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchai
     DeviceCtx *dc = cur_dev();
     if (!dc) return MCMCHIP_EHIP;
     if (!t || !states || !out || nchain <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_logdens");
+    if (int rc = check_target_device(t)) return rc;
     int w = is_temper_kind(t->kind) ? t->d + 1 : t->d;
     InBuf in;
     OutBuf ob;
@@ -275,6 +343,7 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
     if (!dc) return MCMCHIP_EHIP;
     if (!t || !a || !o) return set_error(MCMCHIP_EINVAL, "null argument");
     if (is_temper_kind(t->kind)) return set_error(MCMCHIP_EINVAL, "descriptor kind %d is a tempering target", t->kind);
+    if (int rc = check_target_device(t)) return rc;
     // argument checks in the reference's order and words (metrop.c:40-74)
     if (!a->initial) return set_error(MCMCHIP_EINVAL, "argument \"initial\" must be numeric");
     if (!a->scale) return set_error(MCMCHIP_EINVAL, "argument \"scale\" must be numeric");
@@ -295,6 +364,10 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
     if (!a->device_ptrs) {
         for (size_t i = 0; i < (size_t)nchain * d; i++)
             if (!isfinite(a->initial[i])) return set_error(MCMCHIP_EINVAL, "all elements of \"state\" must be finite");
+    } else {
+        int bits = 0;
+        if (int rc = device_validate(dc, a->initial, nchain * d, 1, 0, &bits)) return rc;
+        if (bits & VAL_NONFINITE) return set_error(MCMCHIP_EINVAL, "all elements of \"state\" must be finite");
     }
     // output functional -> index map (metrop.c:416-503 already resolved to a mask by the caller)
     std::vector<int> map;
@@ -321,7 +394,7 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
     }
     if (a->debug && (!o->current || !o->proposal || !o->z || !o->log_green || !o->u || !o->debug_accept))
         return set_error(MCMCHIP_EINVAL, "debug requested but trace outputs are NULL");
-    if (!o->accept || !o->batch || !o->final || !o->accept_batch) return set_error(MCMCHIP_EINVAL, "null output");
+    if (!o->accept || (!o->batch && nout > 0) || !o->final || !o->accept_batch) return set_error(MCMCHIP_EINVAL, "null output");
 
     bool mfma_ok = t->xt && !a->debug && !t->morph_flags;
     bool mfma = (a->path == MCMCHIP_PATH_MFMA) || (a->path == MCMCHIP_PATH_AUTO && mfma_ok && mfma_pays(t, nchain));
@@ -339,7 +412,8 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
         HIP_TRY(u.set(a->u, (size_t)nchain * niter * 8, dp, s));
     }
     HIP_TRY(accept.set(o->accept, (size_t)nchain * 8, dp));
-    HIP_TRY(batch.set(o->batch, (size_t)nchain * a->nbatch * (nout ? nout : 1) * 8, dp));
+    // nout == 0 is legal (an all-FALSE logical outfun: the reference returns an nbatch x 0 batch): nothing is staged or copied back
+    HIP_TRY(batch.set(o->batch, (size_t)nchain * a->nbatch * nout * 8, dp));
     HIP_TRY(final_.set(o->final, (size_t)nchain * d * 8, dp));
     HIP_TRY(accb.set(o->accept_batch, (size_t)nchain * a->nbatch * 8, dp));
     if (a->debug) {
@@ -408,6 +482,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     if (!dc) return MCMCHIP_EHIP;
     if (!t || !a || !o) return set_error(MCMCHIP_EINVAL, "null argument");
     if (!is_temper_kind(t->kind)) return set_error(MCMCHIP_EINVAL, "descriptor kind %d is not a tempering target", t->kind);
+    if (int rc = check_target_device(t)) return rc;
     const int k = a->ncomp, p = t->d;
     // temper.c:29-95 checks
     if (!a->neighbors) return set_error(MCMCHIP_EINVAL, "argument \"neighbors\" must be logical");
@@ -416,6 +491,15 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
         for (int j = 0; j < k; j++)
             if ((a->neighbors[i + k * j] != 0) != (a->neighbors[j + k * i] != 0))
                 return set_error(MCMCHIP_EINVAL, "argument \"neighbors\" must be symmetric matrix");
+    // neighbour counts (temper.c:497-502).  A TRUE diagonal is legal input (only symmetry is checked), so a row can hold
+    // up to k neighbours; a row with none makes the reference index the_neighbors[i][-1] (temper.c:699,795): refused.
+    int maxnn = 0;
+    for (int i = 0; i < k; i++) {
+        int deg = 0;
+        for (int j = 0; j < k; j++) deg += a->neighbors[i + k * j] != 0;
+        if (deg == 0) return set_error(MCMCHIP_EINVAL, "component %d of \"neighbors\" has no neighbors", i + 1);
+        if (deg > maxnn) maxnn = deg;
+    }
     if (!a->initial) return set_error(MCMCHIP_EINVAL, "argument \"initial\" must be real");
     if (a->nens <= 0) return set_error(MCMCHIP_EINVAL, "nens must be positive");
     if (a->nbatch <= 0) return set_error(MCMCHIP_EINVAL, "argument \"nbatch\" must be positive");
@@ -436,6 +520,12 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
                 if (i != ri) return set_error(MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be integer in serial case");
                 if (i <= 0 || i > k) return set_error(MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be in 1, ..., k in serial case");
             }
+    } else {
+        int bits = 0;
+        if (int rc = device_validate(dc, a->initial, nens * nstate, nstate, a->parallel ? 0 : k, &bits)) return rc;
+        if (bits & VAL_NONFINITE) return set_error(MCMCHIP_EINVAL, "argument \"initial\" must have all elements finite");
+        if (bits & VAL_NOTINT) return set_error(MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be integer in serial case");
+        if (bits & VAL_RANGE) return set_error(MCMCHIP_EINVAL, "1st elem of argument \"initial\" must be in 1, ..., k in serial case");
     }
     size_t slen1;
     switch (a->scale_kind & 7) {
@@ -503,7 +593,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     q.kind = t->kind; q.p = p; q.par = t->par; q.npar = t->npar;
     q.x = t->x; q.y = t->y; q.n = t->n; q.prior_c = t->prior_c;
     q.nens = nens; q.k = k; q.parallel = a->parallel; q.nbatch = a->nbatch; q.blen = a->blen; q.nspac = a->nspac;
-    q.neighbors = nbrs.as<int>(); q.initial = init.as<double>();
+    q.neighbors = nbrs.as<int>(); q.maxnn = maxnn; q.initial = init.as<double>();
     q.scale_kind = a->scale_kind; q.scale = scale.as<double>();
     q.rng_mode = a->rng_mode; q.unif = unif.as<double>(); q.norm = norm.as<double>();
     q.seed = a->seed; q.ens_offset = a->ens_offset; q.iter_offset = a->iter_offset;

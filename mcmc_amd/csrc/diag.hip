@@ -134,40 +134,69 @@ __global__ void autocov_reduce_kernel(const double *__restrict__ partial, long n
     out[idx] = s;
 }
 
-// host post-processing of one column, in the reference's order (initseq.c:49-105)
-static void initseq_finish(const std::vector<double> &Gam, long m, double g0, double *Gpos, double *Gdec,
-                           double *Gcon, double *vpos, double *vdec, double *vcon)
+// Host post-processing of one column's Gamma sequence (a few hundred numbers).  What initseq.c:49-105 returns:
+//   Gamma.pos  the sequence as computed (truncated at the first negative term, which is stored as 0),
+//   Gamma.dec  its greatest non-increasing minorant = running minimum,
+//   Gamma.con  its greatest convex minorant: isotonic regression (pool adjacent violators) of the slopes of
+//              Gamma.dec, integrated back from Gamma.dec[0],
+//   var.*      2 * sum(Gamma.*) - gamma0.
+// The pooled slopes are kept as a stack of {sum, count} blocks; block means are compared as sum / count and
+// merged by adding sums, and the convex sequence is rebuilt by repeated addition of the block mean: the same
+// floating-point operations in the same order as the reference, so results agree bit for bit with its arithmetic.
+namespace {
+struct SlopeBlock {
+    double sum;     // sum of the slopes pooled into this block
+    long count;     // how many
+    double mean() const { return sum / count; }
+};
+
+struct GammaOut {
+    double *pos, *dec, *con;
+    double *var_pos, *var_dec, *var_con;
+};
+
+double twice_sum_minus(const double *v, long m, double g0)
 {
-    std::vector<double> buff(Gam.begin(), Gam.begin() + m);
-    for (long j = 0; j < m; ++j) Gpos[j] = buff[j];
-    for (long j = 1; j < m; ++j)
-        if (buff[j] > buff[j - 1]) buff[j] = buff[j - 1];
-    for (long j = 0; j < m; ++j) Gdec[j] = buff[j];
-    for (long j = m - 1; j > 0; --j) buff[j] -= buff[j - 1];
-    std::vector<double> puff((size_t)(m > 0 ? m : 1));
-    std::vector<long> nuff((size_t)(m > 0 ? m : 1));
-    long nstep = 0;
-    for (long j = 1; j < m; ++j) {
-        puff[nstep] = buff[j];
-        nuff[nstep] = 1;
-        ++nstep;
-        while (nstep > 1 && puff[nstep - 1] / nuff[nstep - 1] < puff[nstep - 2] / nuff[nstep - 2]) {
-            puff[nstep - 2] += puff[nstep - 1];
-            nuff[nstep - 2] += nuff[nstep - 1];
-            --nstep;
+    double s = 0.0;
+    for (long j = 0; j < m; ++j) s += v[j];
+    return 2.0 * s - g0;
+}
+
+void gamma_sequences(const double *G, long m, double g0, const GammaOut &o)
+{
+    if (m > 0) {
+        // running minimum
+        double low = G[0];
+        for (long j = 0; j < m; ++j) {
+            o.pos[j] = G[j];
+            if (!(G[j] > low)) low = G[j];
+            o.dec[j] = low;
+        }
+        // isotonic regression of the slopes dec[j] - dec[j-1], j = 1..m-1, by pooling adjacent violators
+        std::vector<SlopeBlock> pool;
+        pool.reserve((size_t)m);
+        for (long j = 1; j < m; ++j) {
+            pool.push_back(SlopeBlock{o.dec[j] - o.dec[j - 1], 1});
+            while (pool.size() > 1 && pool.back().mean() < pool[pool.size() - 2].mean()) {
+                const SlopeBlock top = pool.back();
+                pool.pop_back();
+                pool.back().sum += top.sum;
+                pool.back().count += top.count;
+            }
+        }
+        // integrate the pooled slopes back
+        o.con[0] = o.dec[0];
+        long j = 1;
+        for (const SlopeBlock &b : pool) {
+            const double slope = b.mean();
+            for (long r = 0; r < b.count; ++r, ++j) o.con[j] = o.con[j - 1] + slope;
         }
     }
-    for (long js = 0, j = 1; js < nstep; ++js) {
-        double muff = puff[js] / nuff[js];
-        for (long q = 0; q < nuff[js]; ++j, ++q) buff[j] = buff[j - 1] + muff;
-    }
-    for (long j = 0; j < m; ++j) Gcon[j] = buff[j];
-    double vp = 0.0, vd = 0.0, vc = 0.0;
-    for (long j = 0; j < m; ++j) { vp += Gpos[j]; vd += Gdec[j]; vc += Gcon[j]; }
-    *vpos = vp * 2.0 - g0;
-    *vdec = vd * 2.0 - g0;
-    *vcon = vc * 2.0 - g0;
+    *o.var_pos = twice_sum_minus(o.pos, m, g0);
+    *o.var_dec = twice_sum_minus(o.dec, m, g0);
+    *o.var_con = twice_sum_minus(o.con, m, g0);
 }
+}  // namespace
 
 int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0, double *Gpos,
                 double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon, DeviceCtx *dc)
@@ -277,7 +306,17 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
                 const long i = lag_first / 2 + q;
                 if (i >= half) { done[(size_t)c] = half; fin = true; break; }
                 const double gam1 = g[2 * q] / len, gam2 = g[2 * q + 1] / len;    // initseq.c:30,39
-                if (i == 0) g0[(size_t)c] = gam1;
+                if (i == 0) {
+                    g0[(size_t)c] = gam1;
+                    // the lag-0 sum of squares is finite iff every element is (short of overflow): this is where a
+                    // series handed over as a device pointer gets the reference's finiteness check (initseq.c:15)
+                    if (!std::isfinite(gam1)) {
+                        int bits = 0;
+                        if (int rc = device_validate(dc, x + (size_t)c * len, len, 1, 0, &bits)) return rc;
+                        if (bits) return set_error(MCMCHIP_EINVAL, "all elements of argument must be finite");
+                        return set_error(MCMCHIP_EDOMAIN, "initseq: the lag-0 sum of squares of column %ld overflows", (long)c);
+                    }
+                }
                 double G = gam1 + gam2;
                 if (G < 0.0) {                                                    // initseq.c:42-46
                     Gam[(size_t)c].push_back(0.0);
@@ -300,8 +339,8 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
         n_out[c] = m;
         gamma0[c] = g0[(size_t)c];
         if (m > cap) { overflow = true; continue; }
-        initseq_finish(Gam[(size_t)c], m, g0[(size_t)c], Gpos + (size_t)c * cap, Gdec + (size_t)c * cap,
-                       Gcon + (size_t)c * cap, vpos + c, vdec + c, vcon + c);
+        gamma_sequences(Gam[(size_t)c].data(), m, g0[(size_t)c],
+                        GammaOut{Gpos + (size_t)c * cap, Gdec + (size_t)c * cap, Gcon + (size_t)c * cap, vpos + c, vdec + c, vcon + c});
     }
     if (overflow) return set_error(MCMCHIP_ECAP, "initseq: output capacity too small; required lengths are in n_out");
     return MCMCHIP_OK;

@@ -57,6 +57,7 @@ struct TemperDev {
     long nens;
     int k, parallel, nbatch, blen, nspac;
     const int *neighbors;     // k x k
+    int maxnn;                // largest number of neighbours of a component (host-counted)
     const double *initial;
     int scale_kind;
     const double *scale;
@@ -72,6 +73,9 @@ struct TemperDev {
     int *flag;
 };
 int launch_temper(const TemperDev &p, hipStream_t s);
+
+// capi.hip: VAL_* bits of a device-resident input (non-finite values; serial-tempering component index)
+int device_validate(DeviceCtx *dc, const double *v, long n, long stride, int k, int *bits);
 
 // diag.hip
 int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0,

@@ -744,23 +744,11 @@ int launch_temper(const TemperDev &q, hipStream_t s)
 {
     if (q.p > TEMPER_MAXP) return set_error(MCMCHIP_EINVAL, "tempering path supports state dimension <= %d", TEMPER_MAXP);
     if (q.k > 4096) return set_error(MCMCHIP_EINVAL, "too many components");
-    // the neighbour table is needed on the host only for its maximum degree: it is a host array
-    // in the C-ABI, but here we only hold the device copy; bound the degree by k
+    // maximum degree of the neighbour graph, counted by mcmchip_temper on the caller's host array (a TRUE diagonal
+    // is legal, temper.c:38-41 only asks for symmetry, so a row may hold up to k neighbours)
     const int k = q.k, p = q.p;
-    int maxnn = k - 1 > 0 ? k - 1 : 1;
-    if (maxnn > 8) {
-        // copy back the 0/1 matrix to find the true maximum degree (small: k*k ints)
-        std::vector<int> h((size_t)k * k);
-        HIP_TRY(hipMemcpyAsync(h.data(), q.neighbors, (size_t)k * k * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        int m = 1;
-        for (int i = 0; i < k; i++) {
-            int c = 0;
-            for (int j = 0; j < k; j++) c += h[i + k * j] != 0;
-            if (c > m) m = c;
-        }
-        maxnn = m;
-    }
+    const int maxnn = q.maxnn;
+    if (maxnn < 1 || maxnn > k) return set_error(MCMCHIP_EINVAL, "bad neighbour degree %d", maxnn);
     // run-parallel kernel for the common parallel-tempering shape (faster than temper_kernel from k = 4 up, measured);
     // everything else takes temper_kernel
     const bool run_ok = q.parallel && !q.debug && k <= 64 && p >= 1 && p <= 4 && maxnn <= 8 &&
