@@ -372,6 +372,8 @@ void orc_logdens(const mcmchip_target_desc *t, const double *states, int64_t nch
 {
     int temper_kind = (t->kind == MCMCHIP_T_WITCH || t->kind == MCMCHIP_T_TEMPERED_NORMMIX ||
                        t->kind == MCMCHIP_T_LOGISTIC_MODELS);
+    /* chains are independent: spread them over the host cores when one evaluation is long (the C3 checks) */
+#pragma omp parallel for schedule(dynamic, 1) if (nchain > 1 && t->n >= 100000)
     for (int64_t c = 0; c < nchain; c++) {
         if (temper_kind) {
             const double *s = states + (size_t)c * (t->d + 1);
@@ -839,6 +841,11 @@ int orc_temper(const mcmchip_target_desc *t, const mcmchip_temper_args *a, mcmch
         for (int j = 0; j < k; j++)
             if ((a->neighbors[i + k * j] != 0) != (a->neighbors[j + k * i] != 0))
                 return fail(err, errlen, MCMCHIP_EINVAL, "argument \"neighbors\" must be symmetric matrix");
+    for (int i = 0; i < k; i++) {      /* the reference indexes the_neighbors[i][-1] for such a row (temper.c:699,795) */
+        int deg = 0;
+        for (int j = 0; j < k; j++) deg += a->neighbors[i + k * j] != 0;
+        if (!deg) return fail(err, errlen, MCMCHIP_EINVAL, "component of \"neighbors\" has no neighbors");
+    }
     if (a->nbatch <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"nbatch\" must be positive");
     if (a->blen <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"blen\" must be positive");
     if (a->nspac <= 0) return fail(err, errlen, MCMCHIP_EINVAL, "argument \"nspac\" must be positive");

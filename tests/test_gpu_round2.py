@@ -1,0 +1,431 @@
+"""GPU tests added in round 2 (-m gpu): regression tests for the advisor's findings, the configuration bench.py
+times, C5 beyond 2^31 elements, statistical equivalence under the device RNG, chunked persistent kernels."""
+import os
+
+import numpy as np
+import pytest
+
+from mcmc_amd import abi
+from rhelpers import glm_binomial, load_logit
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def api():
+    from mcmc_amd import api as a
+    a.init(0)
+    return a
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+# ----------------------------------------------------------------------------- advisor findings (round 1)
+@pytest.mark.parametrize("parallel", [True, False])
+@pytest.mark.parametrize("k", [4, 9, 12])
+def test_temper_true_diagonal_neighbors(api, oracle_mod, parallel, k):
+    """temper.c:38-41 only asks for a symmetric matrix: a TRUE diagonal is legal and gives rows of degree up to k
+    (a swap of a component with itself always accepts).  Both kernels against the oracle."""
+    rng = np.random.default_rng(k)
+    p, E, nbatch, blen, nspac = 3, 12, 9, 4, 2
+    niter = nbatch * blen * nspac
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    nb = np.ones((k, k), dtype=bool) if k <= 9 else (np.abs(np.subtract.outer(np.arange(k), np.arange(k))) <= 1)
+    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+    init = np.zeros((E, k, p)) if parallel else np.column_stack([rng.integers(1, k + 1, E).astype(float), np.zeros((E, p))])
+    ref = oracle_mod.temper(oracle_mod.Target(abi.T_WITCH, p, par=par), init, nb, nbatch, blen, nspac, 0.4,
+                            parallel=parallel, unif=unif, norm=norm)
+    paths = [abi.PATH_LDS] + ([abi.PATH_RUN] if parallel and nb.sum(axis=1).max() <= 8 else [])
+    for path in paths:
+        o = api.temper(api.Target(abi.T_WITCH, p, par=par), init, nb, nbatch, blen, nspac, 0.4, parallel=parallel,
+                       unif=unif, norm=norm, _path=path)
+        assert np.array_equal(o["final"], ref["final"])
+        assert np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True)
+        assert np.array_equal(o["accepti"], ref["accepti"], equal_nan=True)
+        assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
+    if parallel:
+        assert np.all(np.nan_to_num(np.diagonal(ref["accepti"], axis1=1, axis2=2), nan=1.0) == 1.0)   # self swaps always accept
+
+
+def test_temper_component_without_neighbors_is_refused(api):
+    k, p = 4, 2
+    nb = np.zeros((k, k), dtype=bool)
+    nb[0, 1] = nb[1, 0] = nb[1, 2] = nb[2, 1] = True          # component 4 has no neighbour
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    with pytest.raises(api.McmcHipError, match="has no neighbors"):
+        api.temper(api.Target(abi.T_WITCH, p, par=par), np.zeros((k, p)), nb, 5, 1, 1, 0.3, parallel=True, seed=1)
+
+
+@pytest.mark.parametrize("path", [abi.PATH_STREAM, abi.PATH_MFMA])
+def test_metrop_empty_outfun(api, oracle_mod, path):
+    """an all-FALSE logical outfun is legal (metrop.c:435-444): the batch is nbatch x 0 and nothing is copied back"""
+    rng = np.random.default_rng(8)
+    n, d, C, nbatch = 2048, 8, 64, 6
+    X = rng.standard_normal((n, d)) / 3
+    y = (rng.random(n) < 0.5).astype(float)
+    init = 0.05 * rng.standard_normal((C, d))
+    z, u = rng.standard_normal((C, nbatch, d)), rng.random((C, nbatch))
+    guard = np.full(16, 7.25)
+    o = api.metrop(api.logistic_target(X, y), init, nbatch, scale=0.05, outfun=np.zeros(d, dtype=bool), z=z, u=u, path=path)
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), init, nbatch, scale=0.05, z=z, u=u)
+    assert o["batch"].shape == (C, nbatch, 0)
+    assert np.array_equal(o["final"], ref["final"]) and np.array_equal(o["accept"], ref["accept"])
+    assert np.all(guard == 7.25)
+
+
+def test_descriptor_parameter_block_lengths(api):
+    d = 3
+    with pytest.raises(api.McmcHipError, match="parameter block"):
+        api.Target(abi.T_MVNORM, d, par=np.zeros(d + d * d - 1))
+    with pytest.raises(api.McmcHipError, match="parameter block"):
+        api.Target(abi.T_NORMMIX, d, par=abi.normmix_par([0.5, 0.5], np.zeros((2, d)), 1.0)[:-1])
+    with pytest.raises(api.McmcHipError, match="parameter block"):
+        api.Target(abi.T_NORMMIX, d, par=np.concatenate([[2.5], np.zeros(2 * (2 + d))]))
+    good = np.concatenate([[3.0], [1.0, 0.5, 0.2], abi.normmix_par([1.0], np.zeros((1, d)), 1.0)])
+    api.Target(abi.T_TEMPERED_NORMMIX, d, par=good)
+    with pytest.raises(api.McmcHipError, match="parameter block"):
+        api.Target(abi.T_TEMPERED_NORMMIX, d, par=good[:-2])
+
+
+def test_device_pointer_inputs_are_validated(api):
+    """device_ptrs = 1: the reference's finiteness / component-range checks run on the device"""
+    import ctypes as C
+    import torch
+    L = api.load_library()
+    dev = torch.device("cuda", 0)
+    X, y = load_logit()
+    tg = api.logistic_target(X, y)
+    Cn, d, nbatch = 8, 5, 4
+    init = torch.zeros((Cn, d), dtype=torch.float64, device=dev)
+    init[3, 2] = float("inf")
+    outs = [torch.empty(s, dtype=torch.float64, device=dev) for s in ((Cn,), (Cn, nbatch, d), (Cn, d), (Cn, nbatch))]
+    scale = np.array([0.4])
+    args = abi.MetropArgs(Cn, nbatch, 1, 1, init.data_ptr(), abi.SCALE_CONSTANT, scale.ctypes.data, abi.OUT_IDENTITY, None,
+                          abi.RNG_PHILOX, None, None, 1, 0, 0, 0, 1, abi.PATH_STREAM)
+    out = abi.MetropOut(*[t.data_ptr() for t in outs], None, None, None, None, None, None, 0, 0, 0)
+    assert L.mcmchip_metrop(tg.handle, C.addressof(args), C.addressof(out)) == abi.EINVAL
+    assert b'all elements of "state" must be finite' in L.mcmchip_last_error()
+    init[3, 2] = 0.0
+    assert L.mcmchip_metrop(tg.handle, C.addressof(args), C.addressof(out)) == 0
+    # serial tempering: component index out of range / not an integer / non-finite
+    k, p, E = 4, 2, 6
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    wt = api.Target(abi.T_WITCH, p, par=par)
+    nb = np.ascontiguousarray((np.abs(np.subtract.outer(np.arange(k), np.arange(k))) == 1).astype(np.int32))
+    for bad, msg in ((9.0, b"must be in 1, ..., k"), (1.5, b"must be integer"), (float("nan"), b"all elements finite")):
+        ini = torch.zeros((E, 1 + p), dtype=torch.float64, device=dev)
+        ini[:, 0] = 1.0
+        ini[4, 0] = bad
+        b_, ib, ax, ai, fin = (torch.empty(s, dtype=torch.float64, device=dev)
+                               for s in ((E, p, 3), (E, k, 3), (E, k), (E, k, k), (E, 1 + p)))
+        ta = abi.TemperArgs(E, k, 0, 3, 1, 1, nb.ctypes.data, ini.data_ptr(), abi.SCALE_CONSTANT, scale.ctypes.data,
+                            abi.RNG_PHILOX, None, None, 1, 0, 0, 1, 0, 0, 0)
+        to = abi.TemperOut(b_.data_ptr(), ib.data_ptr(), ax.data_ptr(), ai.data_ptr(), fin.data_ptr(), 0,
+                           *([None] * 10))
+        assert L.mcmchip_temper(wt.handle, C.addressof(ta), C.addressof(to)) == abi.EINVAL
+        assert msg in L.mcmchip_last_error(), L.mcmchip_last_error()
+    # initseq: a NaN in a device-resident series
+    x = torch.randn(5000, dtype=torch.float64, device=dev)
+    x[1234] = float("nan")
+    n_out = np.zeros(1, dtype=np.int64)
+    g0, vp, vd, vc = (np.empty(1) for _ in range(4))
+    Gp, Gd, Gc = (np.empty((1, 64)) for _ in range(3))
+    rc = L.mcmchip_initseq(x.data_ptr(), 5000, 1, 1, 64, n_out.ctypes.data, g0.ctypes.data, Gp.ctypes.data, Gd.ctypes.data,
+                           Gc.ctypes.data, vp.ctypes.data, vd.ctypes.data, vc.ctypes.data)
+    assert rc == abi.EINVAL and b"all elements of argument must be finite" in L.mcmchip_last_error()
+
+
+# ----------------------------------------------------------------------------- the configuration bench.py times (C3)
+def _synthetic(n, d, seed=42):
+    rng = np.random.default_rng(seed)
+    X = np.empty((n, d))
+    X[:, 0] = 1.0
+    X[:, 1:] = rng.standard_normal((n, d - 1)) / np.sqrt(d)
+    beta = 0.5 * rng.standard_normal(d)
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    return X, y, beta
+
+
+@pytest.fixture(scope="module")
+def c3(api, oracle_mod):
+    """BASELINE config 3 data: n = 1e6, d = 64 (bench.py's synthetic()), one descriptor for all C3 tests"""
+    n, d = 1_000_000, 64
+    X, y, beta = _synthetic(n, d)
+    return dict(n=n, d=d, X=X, y=y, beta=beta, tg=api.logistic_target(X, y),
+                otg=oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125))
+
+
+@pytest.mark.parametrize("C", [65536, 8192])
+def test_c3_bench_shape_logdens(api, oracle_mod, c3, C):
+    """mcmchip_logdens(path = MFMA) at the launch shape bench.py times (65 536 chains: 256 chain blocks, no
+    observation split) and at the per-GPU shape of an 8-way strong split (8192 chains: 32 chain blocks x 32 splits):
+    64 sampled chains against the oracle, ALL chains against a second plan (the same states in 256-chain calls:
+    one chain block, 256 observation splits)"""
+    d = c3["d"]
+    states = c3["beta"] + 1e-3 * np.random.default_rng(C).standard_normal((C, d))
+    got = api.logdens(c3["tg"], states, path=abi.PATH_MFMA)
+    pick = np.random.default_rng(1).choice(C, 64, replace=False)
+    ref = oracle_mod.logdens(c3["otg"], states[pick])
+    assert rel(got[pick], ref) < RTOL
+    other = np.concatenate([api.logdens(c3["tg"], states[i:i + 256], path=abi.PATH_MFMA) for i in range(0, C, 256)])
+    assert rel(got, other) < RTOL
+
+
+@pytest.mark.parametrize("C", [65536, 8192])
+def test_c3_bench_shape_metrop_injected(api, oracle_mod, c3, C):
+    """three lockstep iterations of mcmchip_metrop (MFMA path, injected streams) at bench.py's launch shape and at
+    the 8-way strong-split shape; 32 sampled chains replayed by the oracle: identical accept decisions, bitwise
+    equal final states, batch means within 1e-12 (metrop.c:211-271)"""
+    d = c3["d"]
+    rng = np.random.default_rng(7 + C)
+    nbatch = 3
+    init = c3["beta"] + 1e-3 * rng.standard_normal((C, d))
+    z = rng.standard_normal((C, nbatch, d))
+    u = rng.random((C, nbatch))
+    o = api.metrop(c3["tg"], init, nbatch, scale=4.0e-3, z=z, u=u, path=abi.PATH_MFMA)
+    assert o["path"] == "mfma"
+    pick = np.sort(np.random.default_rng(2).choice(C, 32, replace=False))
+    ref = oracle_mod.metrop(c3["otg"], init[pick], nbatch, scale=4.0e-3, z=z[pick], u=u[pick], nthreads=16)
+    assert np.array_equal(o["accept.batch"][pick], ref["accept_batch"])       # blen = nspac = 1: the decisions
+    assert np.array_equal(o["final"][pick], ref["final"])
+    assert rel(o["batch"][pick], ref["batch"]) < RTOL
+    acc = o["accept"].mean()
+    assert 0.1 < acc < 0.5, acc
+    # every chain, not only the sampled ones: states are either the proposal or the previous state, bit for bit
+    prop = init + 4.0e-3 * z[:, 0]
+    first = o["batch"][:, 0]
+    moved = o["accept.batch"][:, 0] == 1.0
+    assert np.array_equal(first[moved], prop[moved]) and np.array_equal(first[~moved], init[~moved])
+
+
+# ----------------------------------------------------------------------------- C5 beyond 2^31 elements
+def test_c5_offsets_beyond_2_31(api, oracle_mod):
+    """initseq and olbm on a device-resident n x p series with n * p = 3.07e9 > 2^31 elements (24.6 GB): columns 0
+    and 255 hold the same AR(1) series, so every result for them must agree bit for bit (a 32-bit offset anywhere
+    would break that); column 0 against the oracle at that n (1e-10)."""
+    import torch
+    from scipy.signal import lfilter
+    L = api.load_library()
+    dev = torch.device("cuda", 0)
+    n, p, blen = 12_000_000, 256, 1000
+    rng = np.random.default_rng(5)
+    s0 = lfilter([1.0], [1.0, -0.9], rng.standard_normal(n))
+    s0 -= s0.mean()
+    x = torch.empty((p, n), dtype=torch.float64, device=dev)       # column-major n x p
+    col = torch.from_numpy(s0).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    for c in range(p):
+        if c in (0, p - 1):
+            x[c] = col
+        else:                                                       # a share of the common series plus white noise
+            x[c] = (c / p) * col + torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            x[c] -= x[c].mean()
+    torch.cuda.synchronize()
+    cap = 4096
+    n_out = np.zeros(p, dtype=np.int64)
+    g0, vp, vd, vc = (np.empty(p) for _ in range(4))
+    Gp, Gd, Gc = (np.empty((p, cap)) for _ in range(3))
+    rc = L.mcmchip_initseq(x.data_ptr(), n, p, 1, cap, n_out.ctypes.data, g0.ctypes.data, Gp.ctypes.data, Gd.ctypes.data,
+                           Gc.ctypes.data, vp.ctypes.data, vd.ctypes.data, vc.ctypes.data)
+    assert rc == 0, L.mcmchip_last_error()
+    m = int(n_out[0])
+    assert n_out[p - 1] == m and m > 10
+    for arr in (g0, vp, vd, vc):
+        assert arr[0] == arr[p - 1]
+    for arr in (Gp, Gd, Gc):
+        assert np.array_equal(arr[0, :m], arr[p - 1, :m])
+    ref = oracle_mod.initseq(s0)
+    assert len(ref["Gamma.pos"]) == m
+    for key, got in (("gamma0", g0[0]), ("Gamma.pos", Gp[0, :m]), ("Gamma.dec", Gd[0, :m]), ("Gamma.con", Gc[0, :m]),
+                     ("var.pos", vp[0]), ("var.dec", vd[0]), ("var.con", vc[0])):
+        assert np.max(np.abs(np.asarray(got) - np.asarray(ref[key]))) <= 1e-10 * np.max(np.abs(ref[key])), key
+    # olbm over all 256 columns: the two copies give the same row/column of var and the same mean, bit for bit
+    mean = np.zeros(p)
+    var = np.empty((p, p))
+    rc = L.mcmchip_olbm(x.data_ptr(), n, p, blen, mean.ctypes.data, var.ctypes.data, 0, 1)
+    assert rc == 0, L.mcmchip_last_error()
+    assert mean[0] == mean[p - 1]
+    assert var[0, 0] == var[p - 1, p - 1] == var[0, p - 1] == var[p - 1, 0]
+    assert np.array_equal(var[0, 1:p - 1], var[p - 1, 1:p - 1])
+    assert np.array_equal(var, var.T)
+    # the first two columns by a second call (p = 2), against the oracle and against the 256-column call
+    c1 = x[1].cpu().numpy()
+    mean2 = np.zeros(2)
+    var2 = np.empty((2, 2))
+    rc = L.mcmchip_olbm(x.data_ptr(), n, 2, blen, mean2.ctypes.data, var2.ctypes.data, 0, 1)
+    assert rc == 0, L.mcmchip_last_error()
+    ref2, refmean = oracle_mod.olbm(np.column_stack([s0, c1]), blen)
+    scale_ = np.sqrt(np.outer(np.diag(ref2), np.diag(ref2)))
+    assert np.max(np.abs(var2 - ref2) / scale_) < 1e-10
+    assert np.max(np.abs(var[:2, :2] - ref2) / scale_) < 1e-10
+    assert np.allclose(mean2, refmean, rtol=0, atol=1e-12)
+    # the last two columns start beyond element 2^31: same numbers as a call that sees them as columns 0 and 1
+    var3 = np.empty((2, 2))
+    mean3 = np.zeros(2)
+    rc = L.mcmchip_olbm(x[p - 2:].data_ptr(), n, 2, blen, mean3.ctypes.data, var3.ctypes.data, 0, 1)
+    assert rc == 0, L.mcmchip_last_error()
+    assert np.max(np.abs(var3 - var[p - 2:, p - 2:]) / np.sqrt(np.outer(np.diag(var3), np.diag(var3)))) < 1e-10
+    assert var3[1, 1] == var2[0, 0]
+    del x
+    torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------------------- statistical equivalence (N1)
+def test_foo_rout_logistic_section_on_device(api, oracle_mod):
+    """devel/bug/foo.Rout:100-117 (the vignette posterior on the `logit` data, one R session under set.seed(42))
+    printed by the DEVICE: the oracle on the emulated R stream records the normals/uniforms each call drew, the
+    device replays them as injected streams."""
+    from rhelpers import t_conf_int
+    rs = oracle_mod.RStream(42)
+    h = oracle_mod.Target(abi.T_SIMPLEX, 5, par=[0.0])
+    o = oracle_mod.metrop(h, np.zeros(5), 1000, rstream=rs)                      # foo.Rout:26-70: the simplex runs
+    o = oracle_mod.metrop(h, o["final"], 1000, scale=0.1, rstream=rs)            # that precede the logistic section
+    o = oracle_mod.metrop(h, o["final"], 1000, scale=0.1, rstream=rs)            # in the same session
+    o = oracle_mod.metrop(h, o["final"], 1000, 1000, scale=0.1, rstream=rs)
+    X, y = load_logit()
+    x = glm_binomial(X, y)
+    otg, dtg = oracle_mod.Target(abi.T_LOGISTIC, 5, x=X, y=y, prior_c=0.125), api.logistic_target(X, y)
+
+    def replay(x0, scale):
+        ref = oracle_mod.metrop(otg, x0, 1000, scale=scale, rstream=rs, debug=True)
+        u = np.where(np.isnan(ref["u"]), 0.5, ref["u"])
+        dev = api.metrop(dtg, np.asarray(x0, dtype=np.float64)[None], 1000, scale=scale, z=ref["z"], u=u)
+        assert np.array_equal(dev["final"][0], ref["final"][0])
+        return dev, ref["final"][0]
+
+    for sc, expect in [(1.0, 0.019), (0.1, 0.725), (0.3, 0.34), (0.5, 0.153)]:   # foo.Rout:100-112
+        dev, x = replay(x, sc)
+        assert dev["accept"][0] == expect
+    dev, x = replay(x, 0.4)
+    assert np.allclose(t_conf_int(dev["accept.batch"][0]), (0.2211882, 0.2748118), atol=5e-8)   # foo.Rout:113-117
+
+
+def test_c1_device_philox_statistically_equivalent(api, oracle_mod):
+    """C1 (vignette demo: `logit` data, scale 0.4, 1e4 iterations per chain) under the DEVICE RNG, 256 chains with
+    fixed seeds, against an independent long run of the oracle under its own seed:
+      - the acceptance rate lies inside the reference's own 95 % interval (foo.Rout:115),
+      - every coordinate's mean agrees within 4 Monte Carlo standard errors,
+      - the variance of the chain means (batch means with one batch per chain: independent and near normal, so the
+        ratio follows an F law) lies inside the central 99.9 % interval of F(255, 63); the pooled variances of the
+        100-iteration batch means agree within 15 %,
+      - initseq on the device's output gives a variance estimate consistent with the batch-means one."""
+    from scipy import stats
+    X, y = load_logit()
+    mle = glm_binomial(X, y)
+    d, blen, nbatch = 5, 100, 100
+    Cd, Co = 256, 64
+    dev = api.metrop(api.logistic_target(X, y), np.tile(mle, (Cd, 1)), nbatch, blen, scale=0.4, seed=20240611)
+    orc = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), np.tile(mle, (Co, 1)),
+                            nbatch, blen, scale=0.4, seed=977, nthreads=16)
+    acc = dev["accept"].mean()
+    assert 0.2211882 < acc < 0.2748118, acc
+    assert 0.2211882 < orc["accept"].mean() < 0.2748118
+    # means: chains are independent, so the standard error of the grand mean comes from the chain means
+    md, mo = dev["batch"].mean(axis=1), orc["batch"].mean(axis=1)          # (chains, d)
+    se = np.sqrt(md.var(axis=0, ddof=1) / Cd + mo.var(axis=0, ddof=1) / Co)
+    zscore = (md.mean(axis=0) - mo.mean(axis=0)) / se
+    assert np.max(np.abs(zscore)) < 4.0, zscore
+    # variances: of the chain means (exact F law), and of the 100-iteration batch means pooled within chains
+    lo, hi = stats.f.ppf([0.0005, 0.9995], Cd - 1, Co - 1)
+    ratio = md.var(axis=0, ddof=1) / mo.var(axis=0, ddof=1)
+    assert np.all((ratio > lo) & (ratio < hi)), (ratio, lo, hi)
+    vd = dev["batch"].var(axis=1, ddof=1).mean(axis=0)
+    vo = orc["batch"].var(axis=1, ddof=1).mean(axis=0)
+    assert np.all(np.abs(vd / vo - 1.0) < 0.15), vd / vo
+    # initseq on the device's path of batch means (chain 0..7, every coordinate): sigma^2 estimates of the same
+    # functional by the two routes agree within sampling error
+    paths = api.metrop(api.logistic_target(X, y), np.tile(mle, (8, 1)), 10000, 1, scale=0.4, seed=5)["batch"]
+    for c in range(8):
+        res = api.initseq(paths[c])
+        for j in range(d):
+            bm = paths[c][:, j].reshape(100, 100).mean(axis=1).var(ddof=1) * 100       # batch-means estimate
+            assert 0.4 < res[j]["var.con"] / bm < 2.5, (c, j, res[j]["var.con"], bm)
+            assert res[j]["var.con"] > res[j]["gamma0"]                                   # positive autocorrelation
+
+
+# ----------------------------------------------------------------------------- Philox-mode tempering, decision by decision
+def _first_divergence(o, ref):
+    """per ensemble: index of the first iteration whose decision record differs (or -1)"""
+    E, T = o["acceptd"].shape
+    out = np.full(E, -1)
+    for e in range(E):
+        diff = (o["acceptd"][e] != ref["acceptd"][e]) | (o["which"][e] != ref["which"][e]) | \
+               (o["proposal"][e][:, 0] != ref["proposal"][e][:, 0])
+        if diff.any():
+            out[e] = int(np.argmax(diff))
+    return out
+
+
+def _assert_near_tie(o, ref, e, t, bounds=None):
+    """a diverging decision must be a genuine rounding tie: u within rounding of exp(log hastings) on one side, or a
+    coordinate of the proposal within rounding of a discontinuity of the density"""
+    tie = False
+    for r in (o, ref):
+        lh, uh = r["log.hastings"][e][t], r["unif.hastings"][e][t]
+        if np.isfinite(lh) and not np.isnan(uh):
+            tie |= abs(uh - np.exp(lh)) < 1e-9
+    if bounds is not None:
+        th = np.abs(np.concatenate([o["proposal"][e][t, 1:], ref["proposal"][e][t, 1:]]))
+        tie |= np.min(np.abs(th[:, None] - np.concatenate([bounds, [1.0]])[None, :])) < 1e-9
+    assert tie, (e, t)
+
+
+def test_temper_philox_decisions_match_oracle(api, oracle_mod):
+    """device Philox against the oracle's restatement of the same counters: the uniforms are bit-equal, the normals
+    differ in the last bits (ocml vs glibc log / sincos), so states agree to rounding and a decision can only flip
+    at a rounding tie.  The witch's hat is piecewise constant: no flips expected; a handful tolerated if each is a tie."""
+    k, p, E = 6, 3, 32
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    i, j = np.indices((k, k))
+    nb = (np.abs(i - j) == 1) | (np.abs(i - j) == 2)
+    args = (nb, 20, 13, 7, 0.3456789)
+    tg, otg = api.Target(abi.T_WITCH, p, par=par), oracle_mod.Target(abi.T_WITCH, p, par=par)
+    o = api.temper(tg, np.zeros((E, k, p)), *args, parallel=True, seed=11, ens_offset=5, debug=True)
+    ref = oracle_mod.temper(otg, np.zeros((E, k, p)), *args, parallel=True, seed=11, ens_offset=5, debug=True)
+    assert np.array_equal(o["unif.which"], ref["unif.which"])               # the same counters, the same bits
+    div = _first_divergence(o, ref)
+    assert (div >= 0).sum() <= 2, div
+    for e in np.nonzero(div >= 0)[0]:
+        _assert_near_tie(o, ref, e, div[e], bounds=par)
+    same = div < 0
+    assert np.max(np.abs(o["final"][same] - ref["final"][same])) < 1e-9
+    assert np.array_equal(o["acceptx"][same], ref["acceptx"][same], equal_nan=True)
+    assert np.array_equal(o["accepti"][same], ref["accepti"][same], equal_nan=True)
+    assert np.allclose(o["batch"][same], ref["batch"][same], rtol=0, atol=1e-9)
+    # the run-parallel kernel draws the same numbers
+    r = api.temper(tg, np.zeros((E, k, p)), *args, parallel=True, seed=11, ens_offset=5, _path=abi.PATH_RUN)
+    assert np.array_equal(r["final"], o["final"]) and np.array_equal(r["batch"], o["batch"])
+    # restart: a 40-batch run from the start equals the 20-batch run followed by its continuation
+    o20 = api.temper(tg, np.zeros((E, k, p)), *args, parallel=True, seed=11, ens_offset=5)
+    nxt = api.temper(o20)
+    full = api.temper(tg, np.zeros((E, k, p)), nb, 40, 13, 7, 0.3456789, parallel=True, seed=11, ens_offset=5)
+    assert np.array_equal(np.concatenate([o20["batch"], nxt["batch"]], axis=1), full["batch"])
+    assert np.array_equal(nxt["final"], full["final"])
+
+
+def test_serial_tempering_philox_decisions_match_oracle(api, oracle_mod):
+    """the Bayes-factor workload (vignettes/bfst.Rnw): serial tempering over the 8 logistic sub-models, device Philox
+    against the oracle's restatement, decision by decision from the debug traces"""
+    from rhelpers import temp_par_setup
+    X, y, models, masks, betas, nb = temp_par_setup()
+    lpp = np.array([0.0, 0.4, 0.1, 0.9, -0.2, 0.3, 0.5, 1.1])
+    kw = dict(x=X, y=y, prior_c=0.125, par=abi.logistic_models_par(masks, lpp, -4 * np.log(2 * np.sqrt(2 * np.pi))))
+    E = 16
+    init = np.tile(np.concatenate([[8.0], betas[7]]), (E, 1))
+    o = api.temper(api.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init, nb, 30, 10, 3, 0.5, parallel=False, seed=9, debug=True)
+    ref = oracle_mod.temper(oracle_mod.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init, nb, 30, 10, 3, 0.5,
+                            parallel=False, seed=9, debug=True)
+    div = _first_divergence(o, ref)
+    assert (div >= 0).sum() <= 1, div
+    for e in np.nonzero(div >= 0)[0]:
+        _assert_near_tie(o, ref, e, div[e])
+    same = div < 0
+    assert np.max(np.abs(o["final"][same] - ref["final"][same])) < 1e-9
+    assert np.array_equal(o["ibatch"][same], ref["ibatch"][same])
+    assert np.allclose(o["batch"][same], ref["batch"][same], rtol=1e-9, atol=1e-11)
+    assert np.allclose(o["ibatch"].sum(axis=2), 1.0)
