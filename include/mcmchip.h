@@ -264,6 +264,18 @@ void mcmchip_target_destroy(mcmchip_target *t);
 int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchain, int path,
                     int device_ptrs, double *out);
 
+/* mcmchip_logdens_noalloc -- NO COUNTERPART IN THE REFERENCE.  For callers that cannot call hipMalloc: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid allocation.  The fp64 MFMA log density of
+ * mcmchip_logdens(path = MFMA, device_ptrs = 1) with the same launch plan and therefore the same bits, but its
+ * scratch (dimension-major states + per-split partial sums) lives in a fixed device array of
+ * MCMCHIP_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends; the call makes no
+ * hipMalloc / hipFree / event creation.  `states` (nchain x d) and `out` (nchain) are DEVICE pointers on the current
+ * device; t must be a logistic descriptor with d <= 128.  Needs (dpad + nsplit) * ceil(nchain / 256) * 256 doubles
+ * (e.g. 8192 chains at d = 64 with up to 256 observation splits: 20 MiB); beyond the array it returns MCMCHIP_ECAP
+ * with the required size in the message.  Calls on one GPU share the array: calls that overlap on one GPU race. */
+#define MCMCHIP_NOALLOC_SCRATCH_BYTES (32u << 20)
+int mcmchip_logdens_noalloc(const mcmchip_target *t, const double *states, int64_t nchain, double *out);
+
 int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *args, mcmchip_metrop_out *out);
 
 int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *args, mcmchip_temper_out *out);

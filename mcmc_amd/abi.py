@@ -140,6 +140,7 @@ EXPORTS = [
     "mcmchip_target_create",
     "mcmchip_target_destroy",
     "mcmchip_logdens",
+    "mcmchip_logdens_noalloc",
     "mcmchip_metrop",
     "mcmchip_temper",
     "mcmchip_initseq",

@@ -52,6 +52,8 @@ def load_library():
     L.mcmchip_target_destroy.restype = None
     L.mcmchip_logdens.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
     L.mcmchip_logdens.restype = C.c_int
+    L.mcmchip_logdens_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.mcmchip_logdens_noalloc.restype = C.c_int
     L.mcmchip_metrop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mcmchip_metrop.restype = C.c_int
     L.mcmchip_temper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

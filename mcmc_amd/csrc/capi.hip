@@ -126,6 +126,7 @@ int mcmchip_init(int device)
         HIP_TRY(hipMemcpy(D.d_tables, &host, sizeof host, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&D.d_flag, 256));
         HIP_TRY(hipMemset(D.d_flag, 0, 256));
+        if (int rc = mfma_scratch_setup(&D)) return rc;      // this device's address of the no-alloc scratch array
         D.inited = true;
     }
     L.device = device;
@@ -333,6 +334,19 @@ int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchai
     HIP_TRY(ob.finish(dc->stream));
     HIP_TRY(hipStreamSynchronize(dc->stream));
     return MCMCHIP_OK;
+}
+
+// No counterpart in the reference: the MFMA log density for callers that cannot allocate.  Device pointers in and
+// out, scratch in the per-device static array (metrop_mfma.hip), no hipMalloc / hipFree / event creation on this path.
+int mcmchip_logdens_noalloc(const mcmchip_target *t, const double *states, int64_t nchain, double *out)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!t || !states || !out || nchain <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_logdens_noalloc");
+    if (int rc = check_target_device(t)) return rc;
+    if (t->morph_flags) return set_error(MCMCHIP_EINVAL, "the MFMA path does not take a morphed descriptor");
+    return launch_logdens_mfma_noalloc(t, states, nchain, out, dc);
 }
 
 // ---------------------------------------------------------------------------------------------

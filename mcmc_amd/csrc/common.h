@@ -11,6 +11,7 @@
 
 #define MCMCHIP_MAX_DEVICES 16
 #define MCMCHIP_MFMA_MAXD 128
+#define MCMCHIP_NOALLOC_SCRATCH_DOUBLES (4L << 20)   // 32 MiB per GPU (include/mcmchip.h: MCMCHIP_NOALLOC_SCRATCH_BYTES)
 
 struct DeviceCtx {
     bool inited = false;
@@ -22,6 +23,8 @@ struct DeviceCtx {
     // seven hipMalloc/hipFree pairs (~3 ms).  Grows on demand; released after a call when it exceeds MCMCHIP_WS_KEEP.
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // device address of this GPU's copy of the file-scope scratch array of mcmchip_logdens_noalloc (metrop_mfma.hip)
+    double *noalloc_scratch = nullptr;
 };
 #define MCMCHIP_WS_KEEP ((size_t)2 << 30)
 

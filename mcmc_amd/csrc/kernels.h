@@ -45,6 +45,9 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc);
 int launch_logdens_mfma(const mcmchip_target *t, const double *states, long nchain, double *out,
                         DeviceCtx *dc);
 int build_mfma_tiles(mcmchip_target *t, hipStream_t s);
+// allocation-free variant of launch_logdens_mfma on the per-device static scratch array (set up by mcmchip_init)
+int mfma_scratch_setup(DeviceCtx *dc);
+int launch_logdens_mfma_noalloc(const mcmchip_target *t, const double *states, long nchain, double *out, DeviceCtx *dc);
 
 // temper.hip
 struct TemperDev {

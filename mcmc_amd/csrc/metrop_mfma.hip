@@ -412,7 +412,7 @@ __global__ void soa_init_kernel(const double *__restrict__ init, long nchain, in
     long c = idx % ldc;
     int j = (int)(idx / ldc);
     double v = (c < nchain && j < d) ? init[(size_t)c * d + j] : 0.0;
-    state[idx] = v;
+    if (state) state[idx] = v;
     prop[idx] = v;
 }
 
@@ -598,6 +598,59 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
     q.partial = partial.as<double>();
     q.colsum = t->colsum;
     q.state = state.as<double>(); q.prop = prop.as<double>();
+    q.logdens_out = out;
+    hipLaunchKernelGGL(metrop_update_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q, -1L);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return MCMCHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mcmchip_logdens_noalloc: the MFMA log density for callers that cannot allocate (HIP graph capture, serving loops).
+// Its scratch -- the dimension-major copy of the states and the per-split partial sums, which the other entry
+// points take from hipMalloc -- is this file-scope device array.  Every GPU the library runs on holds its own copy
+// (32 MiB) at its own address until the process ends; host code reaches it only through the pointer that
+// hipGetSymbolAddress returned for that device (the array's name is a host-side stand-in, not a device address).
+// Calls on one GPU share the array: calls that overlap on one GPU race.  Nothing in it has to start at zero (the
+// staging kernel writes every padded state, the density kernel every partial sum it later reads).
+static __device__ __align__(256) double mfma_scratch[MCMCHIP_NOALLOC_SCRATCH_DOUBLES];
+
+int mfma_scratch_setup(DeviceCtx *dc)          // mcmchip_init: once per device, with that device current
+{
+    if (dc->noalloc_scratch) return MCMCHIP_OK;
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(mfma_scratch)));
+    if (!ptr) return set_error(MCMCHIP_EHIP, "hipGetSymbolAddress returned a null scratch address");
+    dc->noalloc_scratch = (double *)ptr;
+    return MCMCHIP_OK;
+}
+
+int launch_logdens_mfma_noalloc(const mcmchip_target *t, const double *states, long nchain, double *out, DeviceCtx *dc)
+{
+    if (!t->xt) return set_error(MCMCHIP_EINVAL, "target has no MFMA tiles (not a logistic target with d <= %d)", MCMCHIP_MFMA_MAXD);
+    if (!dc->noalloc_scratch) return set_error(MCMCHIP_EHIP, "the scratch array of this device was not set up by mcmchip_init");
+    hipStream_t s = dc->stream;
+    const MfmaPlan pl = make_plan(t, nchain, dc->num_cu);          // the plan of mcmchip_logdens: same bits
+    const long ldc = pl.ldc;
+    const size_t nprop = (size_t)t->dpad * ldc, npart = (size_t)pl.nsplit * ldc;
+    if (nprop + npart > (size_t)MCMCHIP_NOALLOC_SCRATCH_DOUBLES)
+        return set_error(MCMCHIP_ECAP, "mcmchip_logdens_noalloc: %ld chains of dimension %d need %zu doubles of scratch, the "
+                         "fixed array holds %ld (use mcmchip_logdens)", nchain, t->d, nprop + npart, (long)MCMCHIP_NOALLOC_SCRATCH_DOUBLES);
+    double *prop = dc->noalloc_scratch, *partial = dc->noalloc_scratch + nprop;
+    const long total = (long)nprop;
+    hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, states, nchain, t->d,
+                       t->dpad, ldc, (double *)nullptr, prop);
+    HIP_TRY(hipGetLastError());
+    if (int rc = launch_logdens(pl, t, prop, partial, dc)) return rc;
+    UpdParams q;
+    memset(&q, 0, sizeof q);
+    q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nsplit = pl.nsplit;
+    q.pad_term = (double)t->npad_rows * 0.6931471805599453;
+    q.prior_c = t->prior_c;
+    q.nbatch = q.blen = q.nspac = 1;
+    q.partial = partial;
+    q.colsum = t->colsum;
+    q.state = prop; q.prop = prop;
     q.logdens_out = out;
     hipLaunchKernelGGL(metrop_update_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q, -1L);
     HIP_TRY(hipGetLastError());
