@@ -43,7 +43,8 @@ void timing_reset(const char *name)
     L.ev_used = 0;
     snprintf(L.ev_name, sizeof L.ev_name, "%s", name);
 }
-static const int EV_MAX = 256;
+// one event pair per timed launch; the pool grows with the longest call (EV_MAX only bounds a runaway loop)
+static const int EV_MAX = 1 << 20;
 void timing_begin(hipStream_t s)
 {
     LibCtx &L = lib_ctx();

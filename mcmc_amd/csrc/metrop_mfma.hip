@@ -6,18 +6,25 @@
 // chain-iteration, followed by n softplus evaluations per chain.
 //
 // Per Metropolis iteration two kernels run on the library stream:
-//   logdens_mfma_kernel  grid (C/(64*NC), nsplit): a workgroup of 4 wavefronts owns 64*NC chains
-//       per wave-quarter... precisely: wave w owns NC 16-chain tiles whose Theta fragments stay
-//       in VGPRs for the whole launch (loop invariant); the workgroup streams its share of the
-//       observation tiles of X through a double-buffered LDS ring filled by LDS-DMA
-//       (global_load_lds, 16 B/lane), so X is read once per workgroup from HBM/L2 and each
-//       16-observation tile feeds 16*NC v_mfma_f64_16x16x4_f64 per wave.  The accumulator tile
-//       (4 observations x 1 chain per lane) goes straight through the softplus epilogue
-//       (softplus.h, 28 fp64 VALU ops) and into a per-lane running sum: eta never leaves
-//       registers.  The epilogue of tile t is issued next to the MFMAs of tile t+1.
-//   metrop_update_kernel one lane per chain: fixed-order sum of the nsplit partials (bitwise
-//       reproducible, independent of the number of GPUs), prior term, accept rule
+//   logdens_mfma_kernel  grid (ceil(C / 256), nsplit): a workgroup of MFMA_NW = 8 wavefronts (two per SIMD: the
+//       second fills the dependency gaps of the fp64 MFMA) owns 256 chains; wave w owns MFMA_NC = 2 tiles of 16
+//       chains whose Theta fragments stay in VGPRs for the whole launch (loop invariant).  The workgroup streams
+//       its share of the observation tiles of X through a double-buffered 16 KB LDS ring filled by LDS-DMA
+//       (global_load_lds, 16 B/lane), so X is read once per workgroup from HBM/L2 and each 16-observation tile
+//       feeds 16 * NC v_mfma_f64_16x16x4_f64 per wave.  The accumulator tile (4 observations x 1 chain per lane)
+//       goes straight through the softplus epilogue (softplus.h: 11 VALU instructions per value, a degree-6
+//       expansion of |eta|/2 + log1p(exp(-|eta|)) around the nearest of 2035 grid points held in LDS) and into
+//       a per-lane running sum: eta never leaves registers.  The epilogue of tile t is issued between the MFMAs
+//       of tile t+1.
+//   metrop_update_kernel one lane per chain: fixed-order sum of the nsplit partials, prior term, accept rule
 //       (metrop.c:225-235), state/batch-means bookkeeping, Philox normals and the next proposal.
+//
+// Reproducibility: a log density is the fixed-order sum of nsplit partial sums, and nsplit (make_plan) depends on
+// the number of chains of the CALL.  The same chains run as one call or sharded over calls / GPUs therefore see
+// log densities that can differ in the last bits (<= 1e-12 relative, tests/test_gpu_round2.py::
+// test_c3_bench_shape_logdens), and a decision with u within that distance of exp(delta) could differ; reruns
+// of the same call shape are bitwise reproducible.  The AUTO rule between the stream and MFMA paths also looks
+// at the chain count: a sharded run that must reproduce an unsharded one pins `path`.
 //
 // HBM layout: X is stored once per target as sign-folded fragment-major tiles
 //   xt[tile][kstep][lane] = s_row * X[16*tile + (lane&15)][4*kstep + (lane>>4)],  s = +1 (y==1) / -1 (y==0)

@@ -362,21 +362,7 @@ def test_temper_vs_oracle(api, oracle_mod, parallel, target, scale_kind):
     assert np.all(np.isnan(o["accepti"][0])[~nb])              # NA for non-neighbours (temper.c:896-897)
 
 
-def test_temper_philox_matches_oracle_restatement(api, oracle_mod):
-    k, p, E = 6, 3, 32
-    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
-    i, j = np.indices((k, k))
-    nb = (np.abs(i - j) == 1) | (np.abs(i - j) == 2)
-    o = api.temper(api.Target(abi.T_WITCH, p, par=par), np.zeros((E, k, p)), nb, 20, 13, 7, 0.3456789, parallel=True,
-                   seed=11, ens_offset=5)
-    ref = oracle_mod.temper(oracle_mod.Target(abi.T_WITCH, p, par=par), np.zeros((E, k, p)), nb, 20, 13, 7, 0.3456789,
-                            parallel=True, seed=11, ens_offset=5)
-    # same counter-based draws on both sides; Box-Muller differs by ulps, decisions almost surely equal
-    assert np.allclose(o["acceptx"], ref["acceptx"], atol=0.02)
-    assert np.mean(np.abs(o["final"] - ref["final"]) < 1e-9) > 0.9
-    a = api.temper(o)
-    both = api.temper(o, nbatch=40)
-    assert np.array_equal(both["batch"][:, :20], a["batch"])    # restart continues the stream
+# (the Philox-mode comparison with the oracle, decision by decision, lives in tests/test_gpu_round2.py)
 
 
 @pytest.mark.parametrize("target,p", [("witch", 1), ("witch", 3), ("witch", 4), ("mixture", 2), ("mixture", 3)])
@@ -764,7 +750,7 @@ def test_morph_descriptor_errors(api):
         api.logdens(tg, np.zeros((4, 2)), path=abi.PATH_MFMA)
 
 
-def test_logistic_models_logdens_and_serial_run(api, oracle_mod):
+def test_logistic_models_logdens(api, oracle_mod):
     # tests/temp-par.R:58-60 (finite at the sub-model MLEs) through mcmchip_logdens; then a Philox serial-tempering
     # run replayed by the oracle (the Bayes-factor workload of vignettes/bfst.Rnw: ibatch = time spent per model)
     from rhelpers import temp_par_setup
@@ -777,16 +763,7 @@ def test_logistic_models_logdens_and_serial_run(api, oracle_mod):
     assert np.all(np.isfinite(got)) and np.max(np.abs(got - want)) < 1e-11
     E = 16
     init = np.tile(np.concatenate([[8.0], betas[7]]), (E, 1))
-    o = api.temper(api.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init, nb, 30, 10, 3, 0.5, parallel=False, seed=9)
-    ref = oracle_mod.temper(oracle_mod.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init, nb, 30, 10, 3, 0.5,
-                            parallel=False, seed=9)
-    # device Box-Muller (ocml log/sin/cos) and glibc's differ in the last bits, so states agree to rounding, not
-    # bitwise; a flipped decision would show as an O(1) difference
-    same = np.all(np.abs(o["final"] - ref["final"]) <= 1e-9 * (1 + np.abs(ref["final"])), axis=1)
-    assert same.mean() >= 0.9
-    assert np.array_equal(o["ibatch"][same], ref["ibatch"][same])
-    assert np.allclose(o["batch"][same], ref["batch"][same], rtol=1e-9, atol=1e-11)
-    assert np.allclose(o["ibatch"].sum(axis=2), 1.0)
+    # (the Philox serial-tempering run against the oracle: tests/test_gpu_round2.py::test_serial_tempering_philox_decisions_match_oracle)
     with pytest.raises(api.McmcHipError, match="components"):
         api.temper(api.Target(abi.T_LOGISTIC_MODELS, 4, **kw), init[:, :5], nb[:4, :4], 5, 1, 1, 0.5, parallel=False, seed=1)
 
