@@ -121,6 +121,11 @@ int mcmchip_init(int device)
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         D.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipStreamCreateWithFlags(&D.side[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&D.join_ev[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&D.fork_ev, hipEventDisableTiming));
         SoftplusTables host;
         softplus_tables_init(&host);
         HIP_TRY(hipMalloc((void **)&D.d_tables, sizeof host));

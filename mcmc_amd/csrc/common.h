@@ -23,6 +23,9 @@ struct DeviceCtx {
     // seven hipMalloc/hipFree pairs (~3 ms).  Grows on demand; released after a call when it exceeds MCMCHIP_WS_KEEP.
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // two side streams for launches that may overlap (initseq: HBM-bound short-lag items next to MFMA-bound long ones)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
     // device address of this GPU's copy of the file-scope scratch array of mcmchip_logdens_noalloc (metrop_mfma.hip)
     double *noalloc_scratch = nullptr;
 };
