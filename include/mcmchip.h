@@ -39,6 +39,7 @@ extern "C" {
 #define MCMCHIP_EDOMAIN  2  /* log density -Inf at initial state, or +Inf/NaN anywhere (metrop.c:196-197,317-320) */
 #define MCMCHIP_EHIP     3  /* HIP runtime error */
 #define MCMCHIP_ECAP     4  /* caller-provided output capacity too small (initseq) */
+#define MCMCHIP_EINTR    5  /* the interrupt callback asked to stop between two launches (R_CheckUserInterrupt, metrop.c:269) */
 
 /* ------------------------------------------------------------------ */
 /* log unnormalised density descriptors (replace the R closure `func1`,
@@ -295,6 +296,17 @@ int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs,
  * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned. */
 int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
                  int32_t nocalc, int device_ptrs);
+
+/* Interrupts and launch length.  The reference calls R_CheckUserInterrupt() every iteration (metrop.c:269,
+ * temper.c:848).  Here a sampler call is a sequence of kernel launches of about a quarter of a second each (one
+ * short calibration launch first; the state is carried between launches, results are bit for bit those of a single
+ * launch), and between two launches the host calls `poll(ctx)`: a non-zero return abandons the call, which releases
+ * its device buffers and returns MCMCHIP_EINTR.  An R glue passes a function that runs R_CheckUserInterrupt under
+ * R_ToplevelExec.  poll == NULL (default): no callback.
+ * mcmchip_set_launch_limit: max_iters > 0 fixes the iterations per launch (tests; tempering rounds it up to whole
+ * 64-iteration windows), 0 restores the time-based rule; budget_seconds > 0 changes the quarter second. */
+int mcmchip_set_interrupt_poll(int (*poll)(void *ctx), void *ctx);
+int mcmchip_set_launch_limit(int64_t max_iters, double budget_seconds);
 
 /* timing of the most recent call's dominant kernel, measured with HIP events on the
  * library's own stream (bench.py roofline): average ms per launch and launch count */

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-OK, EINVAL, EDOMAIN, EHIP, ECAP = 0, 1, 2, 3, 4
+OK, EINVAL, EDOMAIN, EHIP, ECAP, EINTR = 0, 1, 2, 3, 4, 5
 
 T_LOGISTIC, T_LOGISTIC_NAIVE, T_MVNORM, T_NORMMIX = 1, 2, 3, 4
 T_SIMPLEX, T_BALL, T_WITCH, T_TEMPERED_NORMMIX = 5, 6, 7, 8
@@ -145,6 +145,8 @@ EXPORTS = [
     "mcmchip_temper",
     "mcmchip_initseq",
     "mcmchip_olbm",
+    "mcmchip_set_interrupt_poll",
+    "mcmchip_set_launch_limit",
     "mcmchip_last_kernel_time",
     "mcmchip_sync",
 ]

@@ -66,6 +66,10 @@ def load_library():
     L.mcmchip_last_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
     L.mcmchip_last_kernel_time.restype = C.c_int
     L.mcmchip_sync.restype = C.c_int
+    L.mcmchip_set_interrupt_poll.argtypes = [C.c_void_p, C.c_void_p]
+    L.mcmchip_set_interrupt_poll.restype = C.c_int
+    L.mcmchip_set_launch_limit.argtypes = [C.c_int64, C.c_double]
+    L.mcmchip_set_launch_limit.restype = C.c_int
     _LIB = L
     return L
 
@@ -84,6 +88,28 @@ def init(device=None):
         _check(load_library().mcmchip_init(int(device)))
         _INIT_DEVICE = device
     return device
+
+
+_POLL_KEEPALIVE = None
+
+
+def set_interrupt_poll(fn=None):
+    """fn() is called on the host between two kernel launches of a sampler call (the place of
+    R_CheckUserInterrupt, metrop.c:269 / temper.c:848); a true return abandons the call (McmcHipError, code
+    EINTR).  None removes the callback."""
+    global _POLL_KEEPALIVE
+    if fn is None:
+        cb = None
+        _check(load_library().mcmchip_set_interrupt_poll(None, None))
+    else:
+        cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(lambda _ctx: 1 if fn() else 0)
+        _check(load_library().mcmchip_set_interrupt_poll(C.cast(cb, C.c_void_p), None))
+    _POLL_KEEPALIVE = cb
+
+
+def set_launch_limit(max_iters=0, budget_seconds=0.0):
+    """iterations per kernel launch of the persistent sampler kernels (0: time-based, about budget_seconds each)"""
+    _check(load_library().mcmchip_set_launch_limit(int(max_iters), float(budget_seconds)))
 
 
 def last_kernel_time():

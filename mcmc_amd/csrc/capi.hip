@@ -101,7 +101,56 @@ int device_validate(DeviceCtx *dc, const double *v, long n, long stride, int k, 
     return MCMCHIP_OK;
 }
 
+double timing_last_ms()
+{
+    LibCtx &L = lib_ctx();
+    if (L.ev_used <= 0 || (int)L.ev_stop.size() < L.ev_used) return -1.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(L.ev_stop[L.ev_used - 1]) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, L.ev_start[L.ev_used - 1], L.ev_stop[L.ev_used - 1]) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+long next_launch_iters(long remaining, long last_iters, double last_ms, long align)
+{
+    LibCtx &L = lib_ctx();
+    long c;
+    if (L.max_iters_per_launch > 0) c = L.max_iters_per_launch;
+    else if (last_iters <= 0) c = 256;                      // calibration launch
+    else if (last_ms > 0.0) {
+        const double per_iter_ms = last_ms / (double)last_iters;
+        const double want = L.launch_budget_s * 1e3 / per_iter_ms;
+        c = want > 4e18 ? remaining : (long)want;
+    } else c = last_iters * 4;
+    if (c < 1) c = 1;
+    if (align > 1) c = ((c + align - 1) / align) * align;
+    return c < remaining ? c : remaining;
+}
+
+int poll_interrupt()
+{
+    LibCtx &L = lib_ctx();
+    if (L.poll && L.poll(L.poll_ctx)) return set_error(MCMCHIP_EINTR, "interrupted between two kernel launches");
+    return MCMCHIP_OK;
+}
+
 extern "C" {
+
+int mcmchip_set_interrupt_poll(int (*poll)(void *), void *ctx)
+{
+    lib_ctx().poll = poll;
+    lib_ctx().poll_ctx = ctx;
+    return MCMCHIP_OK;
+}
+
+int mcmchip_set_launch_limit(int64_t max_iters, double budget_seconds)
+{
+    clear_error();
+    if (max_iters < 0) return set_error(MCMCHIP_EINVAL, "max_iters must be >= 0");
+    lib_ctx().max_iters_per_launch = (long)max_iters;
+    if (budget_seconds > 0.0) lib_ctx().launch_budget_s = budget_seconds;
+    return MCMCHIP_OK;
+}
 
 const char *mcmchip_last_error(void) { return g_err; }
 const char *mcmchip_version(void) { return "mcmchip 0.1 (gfx950)"; }
@@ -472,9 +521,7 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
         rc = run_metrop_mfma(t, p, dc);
     } else {
         timing_reset("metrop_stream_kernel");
-        timing_begin(s);
-        rc = launch_metrop_stream(p, s);
-        timing_end(s);
+        rc = launch_metrop_stream(p, s);         // one or more timed launches
     }
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     rc = check_flag(dc, false);     // synchronises; device buffers are released by the destructors
@@ -628,9 +675,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     q.dbg_coproposal = dcop.as<double>();
     q.flag = dc->d_flag;
     timing_reset("temper_kernel");
-    timing_begin(s);
-    int rc = launch_temper(q, s);
-    timing_end(s);
+    int rc = launch_temper(q, s);            // one or more timed launches
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     rc = check_flag(dc, true);
     if (rc) return rc;

@@ -39,6 +39,13 @@ struct LibCtx {
     std::vector<hipEvent_t> ev_start, ev_stop;
     int ev_used = 0;
     char ev_name[64] = {0};
+    // persistent sampler kernels are cut into launches of about launch_budget_s seconds (max_iters_per_launch > 0
+    // fixes the iterations per launch instead); between launches the host calls `poll` (R_CheckUserInterrupt's
+    // place, metrop.c:269 / temper.c:848): a non-zero return abandons the call with MCMCHIP_EINTR
+    int (*poll)(void *) = nullptr;
+    void *poll_ctx = nullptr;
+    long max_iters_per_launch = 0;
+    double launch_budget_s = 0.25;
 };
 
 LibCtx &lib_ctx();
@@ -163,3 +170,10 @@ struct mcmchip_target {
 void timing_reset(const char *name);
 void timing_begin(hipStream_t s);
 void timing_end(hipStream_t s);
+double timing_last_ms();          // waits for the launch timed last and returns its duration (-1: not available)
+
+// launch chunking of the persistent kernels: iterations for the next launch, given the iterations and duration of the
+// previous one (0 iterations: first launch, a short calibration launch); rounded up to a multiple of `align`
+long next_launch_iters(long remaining, long last_iters, double last_ms, long align);
+// host poll point between launches: MCMCHIP_OK, or MCMCHIP_EINTR (error text set) when the caller's callback asks to stop
+int poll_interrupt();

@@ -26,6 +26,11 @@ struct MetropDev {
     const double *z, *u;      // injected streams
     unsigned long long seed, chain_offset, iter_offset;
     int debug;
+    // one launch of the stream kernel: iterations [l_begin, l_end); resume = 1 continues from `final_` and `carry`
+    // (per chain: cached log density, accepted, accepted in this batch, batch accumulator[nout])
+    long l_begin, l_end;
+    int resume;
+    double *carry;
     // chain-major inputs/outputs
     const double *initial;
     double *final_, *accept, *batch, *accept_batch;
@@ -71,6 +76,11 @@ struct TemperDev {
     int debug;
     int out_kind;             // MCMCHIP_TOUT_*
     int path;                 // MCMCHIP_PATH_AUTO | _LDS | _RUN
+    // one launch: iterations [it_begin, it_end) (multiples of 64 except the end of the run); resume = 1 restores the
+    // ensemble's record from `carry`
+    long it_begin, it_end;
+    int resume;
+    double *carry;
     int *dbg_which, *dbg_acceptd;
     double *dbg_unif_which, *dbg_state, *dbg_lh, *dbg_uh, *dbg_proposal, *dbg_norm, *dbg_unif_choose, *dbg_coproposal;
     int *flag;

@@ -563,6 +563,10 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     const long niter = (long)p.nbatch * p.blen * p.nspac;
     dim3 ugrid((unsigned)((p.nchain + 255) / 256)), ublock(256);
     timing_reset("logdens_mfma_kernel");
+    // The iterations are queued asynchronously.  With an interrupt callback registered (metrop.c:269) the host waits
+    // for the queue about every quarter of a second and polls: the first group is one iteration, which calibrates.
+    const bool polled = lib_ctx().poll != nullptr;
+    long group = 1, in_group = 0;
     for (long l = -1; l < niter; l++) {
         timing_begin(s);
         int rc = launch_logdens(pl, t, prop, partial, dc);
@@ -570,6 +574,14 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
         if (rc) return rc;
         hipLaunchKernelGGL(metrop_update_kernel, ugrid, ublock, 0, s, q, l);
         HIP_TRY(hipGetLastError());
+        if (polled && ++in_group >= group && l + 1 < niter) {
+            const double ms = timing_last_ms();      // waits for the last density launch
+            HIP_TRY(hipStreamSynchronize(s));
+            if (int irc = poll_interrupt()) { ws.done(); return irc; }
+            group = ms > 0.0 ? (long)(lib_ctx().launch_budget_s * 1e3 / ms) : 1;
+            if (group < 1) group = 1;
+            in_group = 0;
+        }
     }
     HIP_TRY(hipStreamSynchronize(s));
     ws.done();

@@ -78,12 +78,41 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
         return set_error(MCMCHIP_EINVAL, "state dimension %d too large for the stream path", d);
     const int cpb = 256 / G;
     dim3 grid((unsigned)((p.nchain + cpb - 1) / cpb)), block(256);
-    switch (G) {
-    case 1: return launch_stream_g1(p, lay, grid, s);
-    case 4: return launch_stream_g4(p, lay, grid, s);
-    case 16: return launch_stream_g16(p, lay, grid, s);
-    default: return launch_stream_g64(p, lay, grid, s);
+    // The run as a sequence of launches (see the kernel): a short calibration launch, then launches of about a quarter
+    // of a second, with a host poll point between them.  A run that fits the first launch needs no carry buffer.
+    const long niter = (long)p.nbatch * p.blen * p.nspac;
+    MetropDev q = p;
+    DevBuf carry;
+    long done = 0, last_iters = 0;
+    double last_ms = 0.0;
+    while (done < niter) {
+        const long n = next_launch_iters(niter - done, last_iters, last_ms, 1);
+        q.l_begin = done;
+        q.l_end = done + n;
+        q.resume = done > 0;
+        if (q.l_end < niter && !carry.p) {
+            HIP_TRY(carry.alloc((size_t)p.nchain * (3 + p.nout) * 8));
+            q.carry = carry.as<double>();
+        }
+        int rc;
+        timing_begin(s);
+        switch (G) {
+        case 1: rc = launch_stream_g1(q, lay, grid, s); break;
+        case 4: rc = launch_stream_g4(q, lay, grid, s); break;
+        case 16: rc = launch_stream_g16(q, lay, grid, s); break;
+        default: rc = launch_stream_g64(q, lay, grid, s); break;
+        }
+        timing_end(s);
+        if (rc) return rc;
+        done += n;
+        if (done < niter) {
+            last_ms = timing_last_ms();          // waits for the launch: the host poll point
+            last_iters = n;
+            if (int irc = poll_interrupt()) return irc;
+        }
     }
+    if (carry.p) HIP_TRY(hipStreamSynchronize(s));      // the carry buffer is released on return
+    return MCMCHIP_OK;
 }
 // ---------------------------------------------------------------------------------------------
 // log density of a batch of states (replaces logh(), metrop.c:303-323): 16 lanes per state

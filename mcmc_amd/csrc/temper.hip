@@ -79,19 +79,31 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
         return lud_temper(q.kind, p, gpar, k, comp, th);
     };
 
-    for (int i = lane; i < nstate; i += 64) S[i] = q.initial[(size_t)e * nstate + i];
+    // A launch runs iterations [it_begin, it_end) (launch_temper cuts a run into launches with a host poll point between
+    // them, temper.c:848; boundaries are multiples of 64 iterations, the Philox window).  A resumed launch restores
+    // the ensemble's whole LDS record -- state, cached log densities, batch sums, acceptance counters -- from `carry`.
+    double *carry = q.carry ? q.carry + (size_t)e * lay.ubuf : nullptr;
+    if (q.resume) {
+        for (int i = lane; i < lay.ubuf; i += 64) lds[i] = carry[i];
+    } else {
+        for (int i = lane; i < nstate; i += 64) S[i] = q.initial[(size_t)e * nstate + i];
+        for (int i = lane; i < k; i += 64) {
+            axn[i] = axd[i] = 0;
+            ibuf[i] = 0.0;
+            for (int c2 = 0; c2 < maxnn; c2++) ain[i * maxnn + c2] = aid[i * maxnn + c2] = 0;
+        }
+    }
+    __syncthreads();
     for (int i = lane; i < k; i += 64) {
         int c = 0;
         for (int j = 0; j < k; j++)
             if (q.neighbors[i + k * j]) nb[i * maxnn + c++] = j;   // ascending order (temper.c:504-510)
         nn[i] = c;
-        axn[i] = axd[i] = 0;
-        ibuf[i] = 0.0;
-        for (int c2 = 0; c2 < maxnn; c2++) ain[i * maxnn + c2] = aid[i * maxnn + c2] = 0;
     }
     __syncthreads();
     // cached log densities (temper.c:98-119)
-    if (par && coop) {
+    if (q.resume) {
+    } else if (par && coop) {
         for (int i = 0; i < k; i++) {                    // one wave-cooperative evaluation per component
             for (int j = lane; j < p; j += 64) Y[j] = S[i + k * j];
             __syncthreads();
@@ -137,12 +149,16 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     const bool slist = (q.scale_kind & MCMCHIP_SCALE_LIST) != 0;
     const bool inj = q.rng_mode == MCMCHIP_RNG_INJECTED;
 
-    long it = 0;
-    for (int kb = 0; kb < q.nbatch; kb++) {
-        for (int i = lane; i < nout; i += 64) buf[i] = 0.0;
-        for (int i = lane; i < k; i += 64) ibuf[i] = 0.0;
-        for (int jb = 0; jb < q.blen; jb++) {
-            for (int is = 0; is < q.nspac; is++, it++) {
+    long it = q.it_begin;
+    int is = (int)(it % q.nspac), jb = (int)((it / q.nspac) % q.blen);
+    long kb = it / q.nspac / q.blen;
+    for (; it < q.it_end;) {
+        if (is == 0 && jb == 0) {                       // a batch starts
+            for (int i = lane; i < nout; i += 64) buf[i] = 0.0;
+            for (int i = lane; i < k; i += 64) ibuf[i] = 0.0;
+        }
+        {
+            {
                 const unsigned long long git = q.iter_offset + (unsigned long long)it;
                 double u0, u1, u2 = 0.0, u3 = 0.0;   // which, choose1, choose2, hastings
                 const double *up;
@@ -297,7 +313,10 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
                     }
                 }
                 __syncthreads();
+                it++;
             }
+            if (++is < q.nspac) continue;
+            is = 0;
             // batch accumulation once per blen step (temper.c:851-867)
             if (!corner) {
                 for (int i = lane; i < nout; i += 64) buf[i] += par ? S[i] : S[i + 1];
@@ -318,6 +337,8 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
             }
             if (!par && lane == 0) ibuf[(int)S[0] - 1] += 1.0;
         }
+        if (++jb < q.blen) continue;
+        jb = 0;
         __syncthreads();
         for (int i = lane; i < nout; i += 64)
             q.batch[(size_t)e * q.nbatch * nout + kb + (size_t)q.nbatch * i] = buf[i] / q.blen;   // temper.c:871-879
@@ -325,7 +346,12 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
             for (int i = lane; i < k; i += 64)
                 q.ibatch[(size_t)e * q.nbatch * k + kb + (size_t)q.nbatch * i] = ibuf[i] / q.blen; // temper.c:881-886
         __syncthreads();
+        kb++;
     }
+    __syncthreads();
+    if (carry)
+        for (int i = lane; i < lay.ubuf; i += 64) carry[i] = lds[i];
+    if (q.it_end < niter) return;
     for (int i = lane; i < k; i += 64) q.acceptx[(size_t)e * k + i] = (double)axn[i] / (double)axd[i];  // 0/0 = NaN (temper.c:889-890)
     for (int idx = lane; idx < k * k; idx += 64) {
         const int i = idx % k, j = idx / k;
@@ -410,7 +436,14 @@ __global__ __launch_bounds__(192) void temper_run_kernel(TemperDev q, TemperRunL
         for (int i = threadIdx.x; i < lay.nscale_lds; i += 192) ls[i] = q.scale[i];
         gscale = ls;
     }
-    for (int i = threadIdx.x; i < k * maxnn; i += 192) ain[i] = aid[i] = 0;
+    // A launch runs windows [it_begin / 64, ceil(it_end / 64)).  Carry record of an ensemble (doubles): per lane
+    // x[P], L, acc[P], axn, axd (2 P + 3 values, lane-major), then the k * maxnn pair counters ain, aid.
+    constexpr int CW = 2 * P + 3;
+    double *carry = q.carry ? q.carry + (size_t)e * (64 * CW + 2 * k * maxnn) : nullptr;
+    for (int i = threadIdx.x; i < k * maxnn; i += 192) {
+        ain[i] = q.resume ? (unsigned)carry[64 * CW + i] : 0u;
+        aid[i] = q.resume ? (unsigned)carry[64 * CW + k * maxnn + i] : 0u;
+    }
     const bool live = lane < k;
     const int c = live ? lane : 0;                 // idle lanes shadow component 0 and never commit
     const int sk = q.scale_kind & 7;
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(192) void temper_run_kernel(TemperDev q, TemperRunL
     __syncthreads();
 
     const long niter = (long)q.nbatch * q.blen * q.nspac;
-    const long nwin = (niter + 63) / 64;
+    const long w_begin = q.it_begin / 64, w_end = (q.it_end + 63) / 64;
     const unsigned long long gens = q.ens_offset + (unsigned long long)e;
     const unsigned long long per = (unsigned long long)q.blen * (unsigned long long)q.nspac;   // iterations per batch
     const unsigned nspac = (unsigned)q.nspac;
@@ -433,9 +466,9 @@ __global__ __launch_bounds__(192) void temper_run_kernel(TemperDev q, TemperRunL
 
     if (wave != 0) {
         // ================= producers =================
-        unsigned sp = 0;                       // it0 mod nspac   (wave 1)
-        unsigned long long bp = 0;             // it0 mod per
-        for (long w = 0; w < nwin; w++) {
+        unsigned sp = (unsigned)((unsigned long long)(w_begin * 64) % nspac);      // it0 mod nspac   (wave 1)
+        unsigned long long bp = (unsigned long long)(w_begin * 64) % per;          // it0 mod per
+        for (long w = w_begin; w < w_end; w++) {
             double *wb_ = lds + (w & 1) * lay.wstride;
             const long it0 = w * 64;
             const int nvalid = (int)(niter - it0 < 64 ? niter - it0 : 64);
@@ -536,15 +569,25 @@ __global__ __launch_bounds__(192) void temper_run_kernel(TemperDev q, TemperRunL
         if (par_lds) return lud_temper<lds_cd *>(KIND, P, (lds_cd *)gpar, k, c + 1, th);
         return lud_temper(KIND, P, gpar, k, c + 1, th);
     };
-    double L = LUD_OWN(x);                                            // temper.c:98-119
-    if (live) {
-        if (L == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
-        else if (L == INFINITY) atomicOr(q.flag, FLAG_POSINF);
-        else if (isnan(L)) atomicOr(q.flag, FLAG_NAN);
+    double L;
+    if (!q.resume) {
+        L = LUD_OWN(x);                                               // temper.c:98-119
+        if (live) {
+            if (L == -INFINITY) atomicOr(q.flag, FLAG_NEGINF_INIT);
+            else if (L == INFINITY) atomicOr(q.flag, FLAG_POSINF);
+            else if (isnan(L)) atomicOr(q.flag, FLAG_NAN);
+        }
+    } else {
+        const double *cr = carry + lane * CW;
+#pragma unroll
+        for (int j = 0; j < P; j++) { x[j] = cr[j]; acc[j] = cr[P + 1 + j]; }
+        L = cr[P];
+        axn = (unsigned)cr[2 * P + 1];
+        axd = (unsigned)cr[2 * P + 2];
     }
-    int kb = 0;
-    __syncthreads();                       // window 0 is ready
-    for (long w = 0; w < nwin; w++) {
+    long kb = (long)((unsigned long long)(w_begin * 64) / per);      // batches completed before this launch
+    __syncthreads();                       // the first window is ready
+    for (long w = w_begin; w < w_end; w++) {
         const double *wb_ = lds + (w & 1) * lay.wstride;
         const double *Zbuf = wb_ + lay.zbuf, *U3 = wb_ + lay.u3buf;
         const unsigned *desc = (const unsigned *)(wb_ + lay.desc);
@@ -694,6 +737,19 @@ __global__ __launch_bounds__(192) void temper_run_kernel(TemperDev q, TemperRunL
         }
         __syncthreads();                   // window w consumed; window w+1 is ready
     }
+    if (carry) {
+        double *cr = carry + lane * CW;
+#pragma unroll
+        for (int j = 0; j < P; j++) { cr[j] = x[j]; cr[P + 1 + j] = acc[j]; }
+        cr[P] = L;
+        cr[2 * P + 1] = (double)axn;
+        cr[2 * P + 2] = (double)axd;
+        for (int i = lane; i < k * maxnn; i += 64) {
+            carry[64 * CW + i] = (double)ain[i];
+            carry[64 * CW + k * maxnn + i] = (double)aid[i];
+        }
+    }
+    if (q.it_end < niter) return;
     if (live) {
         q.acceptx[(size_t)e * k + c] = (double)axn / (double)axd;        // 0/0 = NaN (temper.c:889-890)
         int slot = 0;
@@ -740,28 +796,18 @@ static int launch_temper_run(const TemperDev &q, int maxnn, hipStream_t s)
     return MCMCHIP_OK;
 }
 
-int launch_temper(const TemperDev &q, hipStream_t s)
+// one launch of the chosen kernel over q.it_begin .. q.it_end
+static int launch_temper_once(const TemperDev &q, bool run_kernel, hipStream_t s, size_t *carry_doubles)
 {
-    if (q.p > TEMPER_MAXP) return set_error(MCMCHIP_EINVAL, "tempering path supports state dimension <= %d", TEMPER_MAXP);
-    if (q.k > 4096) return set_error(MCMCHIP_EINVAL, "too many components");
-    // maximum degree of the neighbour graph, counted by mcmchip_temper on the caller's host array (a TRUE diagonal
-    // is legal, temper.c:38-41 only asks for symmetry, so a row may hold up to k neighbours)
-    const int k = q.k, p = q.p;
-    const int maxnn = q.maxnn;
-    if (maxnn < 1 || maxnn > k) return set_error(MCMCHIP_EINVAL, "bad neighbour degree %d", maxnn);
-    // run-parallel kernel for the common parallel-tempering shape (faster than temper_kernel from k = 4 up, measured);
-    // everything else takes temper_kernel
-    const bool run_ok = q.parallel && !q.debug && k <= 64 && p >= 1 && p <= 4 && maxnn <= 8 &&
-                        (q.kind == MCMCHIP_T_WITCH || q.kind == MCMCHIP_T_TEMPERED_NORMMIX);
-    if (q.path == MCMCHIP_PATH_RUN && !run_ok)
-        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path needs parallel = 1, debug = 0, k <= 64, p <= 4, "
-                                         "at most 8 neighbours per component and a closed-form descriptor");
-    if (run_ok && q.path != MCMCHIP_PATH_LDS) {
+    const int k = q.k, p = q.p, maxnn = q.maxnn;
+    if (run_kernel) {
+        *carry_doubles = (size_t)64 * (2 * p + 3) + 2 * (size_t)k * maxnn;
 #define RUN_CASE(PP) \
         case PP: return q.kind == MCMCHIP_T_WITCH ? launch_temper_run<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
                                                   : launch_temper_run<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
         switch (p) { RUN_CASE(1) RUN_CASE(2) RUN_CASE(3) RUN_CASE(4) }
 #undef RUN_CASE
+        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path: bad dimension %d", p);
     }
     const int nstate = q.parallel ? k * p : p + 1;
     const int nout = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (q.parallel ? k : 2 * k) : (q.parallel ? k * p : p);
@@ -790,9 +836,67 @@ int launch_temper(const TemperDev &q, hipStream_t s)
     lay.par = o; o += lay.npar_lds;
     lay.scale = o; o += lay.nscale_lds;
     lay.end = o;
+    *carry_doubles = (size_t)lay.ubuf;
     size_t bytes = (size_t)o * 8;
     if (bytes > 64 * 1024) return set_error(MCMCHIP_EINVAL, "tempering state (%zu bytes) does not fit the LDS budget", bytes);
     hipLaunchKernelGGL(temper_kernel, dim3((unsigned)q.nens), dim3(64), bytes, s, q, lay, maxnn);
     HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
+int launch_temper(const TemperDev &q0, hipStream_t s)
+{
+    const TemperDev &q = q0;
+    if (q.p > TEMPER_MAXP) return set_error(MCMCHIP_EINVAL, "tempering path supports state dimension <= %d", TEMPER_MAXP);
+    if (q.k > 4096) return set_error(MCMCHIP_EINVAL, "too many components");
+    // maximum degree of the neighbour graph, counted by mcmchip_temper on the caller's host array (a TRUE diagonal
+    // is legal, temper.c:38-41 only asks for symmetry, so a row may hold up to k neighbours)
+    const int k = q.k, p = q.p;
+    const int maxnn = q.maxnn;
+    if (maxnn < 1 || maxnn > k) return set_error(MCMCHIP_EINVAL, "bad neighbour degree %d", maxnn);
+    // run-parallel kernel for the common parallel-tempering shape (faster than temper_kernel from k = 4 up, measured);
+    // everything else takes temper_kernel
+    const bool run_ok = q.parallel && !q.debug && k <= 64 && p >= 1 && p <= 4 && maxnn <= 8 &&
+                        (q.kind == MCMCHIP_T_WITCH || q.kind == MCMCHIP_T_TEMPERED_NORMMIX);
+    if (q.path == MCMCHIP_PATH_RUN && !run_ok)
+        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path needs parallel = 1, debug = 0, k <= 64, p <= 4, "
+                                         "at most 8 neighbours per component and a closed-form descriptor");
+    const bool run_kernel = run_ok && q.path != MCMCHIP_PATH_LDS;
+    // The run as a sequence of launches (temper.c:848 polls for an interrupt every iteration; here the host does between
+    // launches): a short calibration launch, then about a quarter of a second each, cut at multiples of 64 iterations.
+    const long niter = (long)q.nbatch * q.blen * q.nspac;
+    TemperDev qq = q;
+    DevBuf carry;
+    long done = 0, last_iters = 0;
+    double last_ms = 0.0;
+    while (done < niter) {
+        const long n = next_launch_iters(niter - done, last_iters, last_ms, 64);
+        qq.it_begin = done;
+        qq.it_end = done + n;
+        qq.resume = done > 0;
+        size_t cd = 0;
+        if (qq.it_end < niter && !carry.p) {
+            // size of an ensemble's carry record: ask the launcher (same formula it uses) without launching
+            cd = run_kernel ? (size_t)64 * (2 * p + 3) + 2 * (size_t)k * maxnn
+                            : (size_t)((q.parallel ? k * p : p + 1) + k + 2 * p +
+                                       (q.out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (q.parallel ? k : 2 * k) : (q.parallel ? k * p : p)) + k +
+                                       2 * ((k + 1) / 2) + 3 * ((k * maxnn + 1) / 2) + (k + 1) / 2);
+            HIP_TRY(carry.alloc((size_t)q.nens * cd * 8));
+            qq.carry = carry.as<double>();
+        }
+        size_t cd_used = 0;
+        timing_begin(s);
+        int rc = launch_temper_once(qq, run_kernel, s, &cd_used);
+        timing_end(s);
+        if (rc) return rc;
+        if (cd && cd != cd_used) return set_error(MCMCHIP_EINVAL, "Can't happen: carry record size mismatch (%zu vs %zu)", cd, cd_used);
+        done += n;
+        if (done < niter) {
+            last_ms = timing_last_ms();          // waits for the launch: the host poll point
+            last_iters = n;
+            if (int irc = poll_interrupt()) return irc;
+        }
+    }
+    if (carry.p) HIP_TRY(hipStreamSynchronize(s));      // the carry buffer is released on return
     return MCMCHIP_OK;
 }

@@ -38,8 +38,8 @@ def c2():
     oracle.metrop(ot, init[:64], 2000, scale=0.4, seed=1, nthreads=16)
     cel = time.perf_counter() - t0
     return {"config": "C2 logit 100x5, 4096 chains x %d iterations, Philox" % nb, "chain_iter_per_s": Cn * nb / el,
-            "kernel": name, "kernel_ms": kms, "accept": float(o["accept"].mean()),
-            "softplus_evals_per_s": Cn * nb * 100 / (kms * 1e-3),
+            "kernel": name, "kernel_ms": kms * kn, "kernel_launches": kn, "accept": float(o["accept"].mean()),
+            "softplus_evals_per_s": Cn * nb * 100 / (kms * kn * 1e-3),
             "cpu_oracle_16thr_chain_iter_per_s": 64 * 2000 / cel}
 
 
@@ -74,7 +74,8 @@ def c4():
             t0 = time.perf_counter()
             o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3, parallel=True, seed=3, _path=path)
             el = time.perf_counter() - t0
-            kn, kms, _ = api.last_kernel_time()
+            kn, kms, nl = api.last_kernel_time()
+            kms *= nl                              # the run is a sequence of launches: total kernel time
             same = None if prev is None else bool(all(np.array_equal(prev[n], o[n], equal_nan=True)
                                                       for n in ("final", "batch", "acceptx", "accepti")))
             prev = o
@@ -123,7 +124,8 @@ def c4models():
         t0 = time.perf_counter()
         o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.56789, parallel=parallel, seed=3)
         el = time.perf_counter() - t0
-        kn, kms, _ = api.last_kernel_time()
+        kn, kms, nl = api.last_kernel_time()
+        kms *= nl
         niter = nbatch * blen * nspac
         ot = oracle.Target(abi.T_LOGISTIC_MODELS, 4, **kw)
         t0 = time.perf_counter()

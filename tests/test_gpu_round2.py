@@ -429,3 +429,127 @@ def test_serial_tempering_philox_decisions_match_oracle(api, oracle_mod):
     assert np.array_equal(o["ibatch"][same], ref["ibatch"][same])
     assert np.allclose(o["batch"][same], ref["batch"][same], rtol=1e-9, atol=1e-11)
     assert np.allclose(o["ibatch"].sum(axis=2), 1.0)
+
+
+# ----------------------------------------------------------------------------- chunked persistent kernels
+@pytest.fixture
+def launch_limit(api):
+    yield api.set_launch_limit
+    api.set_launch_limit(0, 0.25)
+    api.set_interrupt_poll(None)
+
+
+@pytest.mark.parametrize("rng", ["philox", "injected"])
+def test_metrop_stream_chunked_equals_one_launch(api, launch_limit, rng):
+    """the persistent stream kernel cut into launches of 7 / 64 / 100 iterations (batches of 5 x 3 iterations straddle
+    the cuts, the Philox look-ahead blocks too) gives the bits of a single launch: batch means, acceptance rates,
+    final state, the debug trace; morphed target and matrix scale included"""
+    from mcmc_amd import morph
+    X, y = load_logit()
+    mle = glm_binomial(X, y)
+    rng_ = np.random.default_rng(31)
+    C, nbatch, blen, nspac, d = 48, 11, 5, 3, 5
+    niter = nbatch * blen * nspac
+    init = mle + 0.05 * rng_.standard_normal((C, d))
+    kw = dict(seed=4242, chain_offset=7) if rng == "philox" else dict(z=rng_.standard_normal((C, niter, d)), u=rng_.random((C, niter)))
+    scale = 0.3 * np.linalg.cholesky(np.eye(d) + 0.2)
+    cases = [(api.logistic_target(X, y), init, scale, "moments2"),
+             (api.Target(abi.T_STUDENT_T, d, par=[3.0], morph=morph(b=0.7, r=0.5, p=3)), rng_.standard_normal((C, d)), 0.8, None)]
+    for tg, ini, sc, outfun in cases:
+        launch_limit(0)
+        one = api.metrop(tg, ini, nbatch, blen, nspac, scale=sc, outfun=outfun, debug=True, path=abi.PATH_STREAM, **kw)
+        assert api.last_kernel_time()[2] == 1
+        for cut in (7, 64, 100):
+            launch_limit(cut)
+            o = api.metrop(tg, ini, nbatch, blen, nspac, scale=sc, outfun=outfun, debug=True, path=abi.PATH_STREAM, **kw)
+            assert api.last_kernel_time()[2] == -(-niter // cut)
+            for key in ("batch", "accept", "accept.batch", "final", "current", "proposal", "z", "log.green", "u", "debug.accept"):
+                assert np.array_equal(o[key], one[key], equal_nan=True), (key, cut)
+
+
+@pytest.mark.parametrize("parallel,path", [(True, abi.PATH_LDS), (True, abi.PATH_RUN), (False, abi.PATH_LDS)])
+@pytest.mark.parametrize("rng", ["philox", "injected"])
+def test_temper_chunked_equals_one_launch(api, launch_limit, parallel, path, rng):
+    """both tempering kernels cut into launches of 64 and 192 iterations (whole 64-iteration windows; batches of
+    13 x 7 = 91 iterations straddle the cuts): same bits as a single launch"""
+    k, p, E = 8, 3, 10
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    i, j = np.indices((k, k))
+    nb = (np.abs(i - j) == 1) | (np.abs(i - j) == 2)
+    nbatch, blen, nspac = 6, 13, 7
+    niter = nbatch * blen * nspac
+    rng_ = np.random.default_rng(5)
+    kw = dict(seed=99, ens_offset=3) if rng == "philox" else dict(unif=rng_.random((E, niter, 4)), norm=rng_.standard_normal((E, niter, p)))
+    init = 0.01 * rng_.standard_normal((E, k, p)) if parallel else np.column_stack([rng_.integers(1, k + 1, E).astype(float), np.zeros((E, p))])
+    tg = api.Target(abi.T_WITCH, p, par=par)
+    for outfun in (None, "witch.corner"):
+        launch_limit(0)
+        one = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3456789, parallel=parallel, outfun=outfun, _path=path, **kw)
+        for cut in (64, 192):
+            launch_limit(cut)
+            o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3456789, parallel=parallel, outfun=outfun, _path=path, **kw)
+            assert api.last_kernel_time()[2] == -(-niter // cut)
+            for key in ("batch", "acceptx", "accepti", "final") + (() if parallel else ("ibatch",)):
+                assert np.array_equal(o[key], one[key], equal_nan=True), (key, cut, outfun)
+    if path == abi.PATH_LDS:                      # the debug trace across launches
+        launch_limit(0)
+        one = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3456789, parallel=parallel, debug=True, **kw)
+        launch_limit(128)
+        o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.3456789, parallel=parallel, debug=True, **kw)
+        for key in ("state", "proposal", "log.hastings", "unif.hastings", "acceptd", "which", "norm", "unif.choose"):
+            assert np.array_equal(o[key], one[key], equal_nan=True), key
+
+
+def test_interrupt_poll_between_launches(api, launch_limit):
+    """the host poll point (R_CheckUserInterrupt's place, metrop.c:269 / temper.c:848): the callback runs between
+    launches and a true return abandons the call with MCMCHIP_EINTR; the library stays usable"""
+    X, y = load_logit()
+    mle = glm_binomial(X, y)
+    tg = api.logistic_target(X, y)
+    calls = []
+    api.set_interrupt_poll(lambda: calls.append(1) or len(calls) >= 3)
+    launch_limit(10)
+    with pytest.raises(api.McmcHipError, match="interrupted") as ei:
+        api.metrop(tg, np.tile(mle, (8, 1)), 100, scale=0.4, seed=1, path=abi.PATH_STREAM)
+    assert ei.value.code == abi.EINTR and len(calls) == 3
+    # the MFMA path polls too (per group of iterations)
+    n, d = 4096, 16
+    rng = np.random.default_rng(3)
+    Xs = rng.standard_normal((n, d)) / 4
+    ys = (rng.random(n) < 0.5).astype(float)
+    calls.clear()
+    launch_limit(10, 1e-5)                       # a 10 microsecond budget: a poll after every iteration
+    with pytest.raises(api.McmcHipError, match="interrupted"):
+        api.metrop(api.logistic_target(Xs, ys), np.zeros((64, d)), 50, scale=0.02, seed=1, path=abi.PATH_MFMA)
+    assert len(calls) == 3
+    launch_limit(10, 0.25)
+    # tempering
+    k, p = 4, 2
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    nb = np.abs(np.subtract.outer(np.arange(k), np.arange(k))) == 1
+    calls.clear()
+    launch_limit(64)
+    with pytest.raises(api.McmcHipError, match="interrupted"):
+        api.temper(api.Target(abi.T_WITCH, p, par=par), np.zeros((4, k, p)), nb, 100, 5, 1, 0.3, parallel=True, seed=1)
+    api.set_interrupt_poll(None)
+    launch_limit(0)
+    o = api.metrop(tg, np.tile(mle, (8, 1)), 100, scale=0.4, seed=1, path=abi.PATH_STREAM)
+    assert o["batch"].shape == (8, 100, 5)
+
+
+def test_time_based_launch_budget(api, launch_limit):
+    """with a tiny time budget the run is cut adaptively (calibration launch of 256 iterations, then by measured
+    rate) and still gives the bits of one launch"""
+    X, y = load_logit()
+    mle = glm_binomial(X, y)
+    tg = api.logistic_target(X, y)
+    init = np.tile(mle, (256, 1))
+    launch_limit(0, 10.0)
+    one = api.metrop(tg, init, 3000, scale=0.4, seed=8, path=abi.PATH_STREAM)
+    n_one = api.last_kernel_time()[2]
+    launch_limit(0, 1e-3)                        # 1 ms per launch
+    o = api.metrop(tg, init, 3000, scale=0.4, seed=8, path=abi.PATH_STREAM)
+    n_cut = api.last_kernel_time()[2]
+    launch_limit(0, 0.25)
+    assert n_one <= 2 and n_cut > n_one
+    assert np.array_equal(o["batch"], one["batch"]) and np.array_equal(o["final"], one["final"])
