@@ -60,50 +60,50 @@ template <int NACC> struct AcShape {
     static constexpr int NSLOT = SA + SB;
 };
 
-// the MFMAs of one piece: NJ lag blocks starting at block j0, over this wave's 512 positions of the staged tile
-template <int NJ> __device__ __forceinline__ void autocov_piece(const double *pa, const double *pb, double *acc)
+// the MFMAs of one piece: NJ lag blocks (any NJ <= 16) over this wave's 512 positions = 32 u-steps of the staged tile.
+// One A and one B fragment read per u-step serve NJ MFMAs; the B fragments of the last NJ steps sit in a register ring
+// that is back in phase after every NJ steps, so 32 steps are floor(32 / NJ) unrolled rounds plus a tail of 32 % NJ.
+template <int NJ, int NSTEP> __device__ __forceinline__ void autocov_round(const double *pa, const double *pb, int s0, double *R, double *acc)
 {
-    double R[NJ];                           // R[m % NJ] = B fragment at u + 16 m
 #pragma unroll
-    for (int m = 0; m < NJ - 1; m++) R[m] = pb[16 * m];
-    for (int s0 = 0; s0 < IS_TILE / 4 / 16; s0 += NJ) {
+    for (int ss = 0; ss < NSTEP; ss++) {
+        const int s_ = s0 + ss;
+        const double fa = pa[16 * s_];
+        R[(ss + NJ - 1) % NJ] = pb[16 * (s_ + NJ - 1)];
 #pragma unroll
-        for (int ss = 0; ss < NJ; ss++) {
-            const int s_ = s0 + ss;
-            const double fa = pa[16 * s_];
-            R[(ss + NJ - 1) % NJ] = pb[16 * (s_ + NJ - 1)];
+        for (int j = 0; j < NJ; j++)
+            acc[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, R[(ss + j) % NJ], acc[j], 0, 0, 0);
+    }
+    // keep the fragment reads of a step next to the MFMAs of the step before it: left alone, the scheduler hoists
+    // all reads of the unrolled body to its top (64 VGPRs at NJ = 16, spills in the 768-lag kernel)
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int j = 0; j < NJ; j++)
-                acc[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, R[(ss + j) % NJ], acc[j], 0, 0, 0);
-        }
-        // keep the fragment reads of a step next to the MFMAs of the step before it: left alone, the scheduler hoists
-        // all 2 NJ reads of the unrolled body to its top (64 VGPRs at NJ = 16, spills in the 768-lag kernel)
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int ss = 0; ss < NJ; ss++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
+    for (int ss = 0; ss < NSTEP; ss++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
 }
 
-// NACC lag blocks as pieces of 16, then 8 / 4 / 2 / 1 (compile-time recursion: static register indices)
+template <int NJ> __device__ __forceinline__ void autocov_piece(const double *pa, const double *pb, double *acc)
+{
+    constexpr int STEPS = IS_TILE / 4 / 16;           // 32 u-steps per wave and tile
+    double R[NJ];                                      // R[m % NJ] = B fragment at u + 16 m
+#pragma unroll
+    for (int m = 0; m < NJ - 1; m++) R[m] = pb[16 * m];
+    for (int s0 = 0; s0 + NJ <= STEPS; s0 += NJ) autocov_round<NJ, NJ>(pa, pb, s0, R, acc);
+    if constexpr (STEPS % NJ != 0) autocov_round<NJ, STEPS % NJ>(pa, pb, STEPS - STEPS % NJ, R, acc);
+}
+
+// NACC lag blocks as one piece up to 16, else as the fewest near-equal pieces (compile-time recursion: static
+// register indices)
 template <int NACC, int J0 = 0> __device__ __forceinline__ void autocov_pieces(const double *pa, const double *pb, double *acc)
 {
-    if constexpr (NACC - J0 >= 16) {
-        autocov_piece<16>(pa, pb + 16 * J0, acc + J0);
-        autocov_pieces<NACC, J0 + 16>(pa, pb, acc);
-    } else if constexpr (NACC - J0 >= 8) {
-        autocov_piece<8>(pa, pb + 16 * J0, acc + J0);
-        autocov_pieces<NACC, J0 + 8>(pa, pb, acc);
-    } else if constexpr (NACC - J0 >= 4) {
-        autocov_piece<4>(pa, pb + 16 * J0, acc + J0);
-        autocov_pieces<NACC, J0 + 4>(pa, pb, acc);
-    } else if constexpr (NACC - J0 >= 2) {
-        autocov_piece<2>(pa, pb + 16 * J0, acc + J0);
-        autocov_pieces<NACC, J0 + 2>(pa, pb, acc);
-    } else if constexpr (NACC - J0 >= 1) {
-        autocov_piece<1>(pa, pb + 16 * J0, acc + J0);
+    constexpr int REST = NACC - J0;
+    if constexpr (REST > 0) {
+        constexpr int NPIECE = (REST + 15) / 16;
+        constexpr int NJ = (REST + NPIECE - 1) / NPIECE;
+        autocov_piece<NJ>(pa, pb + 16 * J0, acc + J0);
+        autocov_pieces<NACC, J0 + NJ>(pa, pb, acc);
     }
 }
 

@@ -5,4 +5,4 @@ set -e
 out=${1:-gpurun_out/c5prof}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-MCMCHIP_TRACE=2 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/trace -o c5 --output-format csv -- python3 $GRAFT_REPO_ROOT/tests/secondary_bench.py c5dev=100000256,256,10000 > $GRAFT_REPO_ROOT/$out/c5dev.log 2> $GRAFT_REPO_ROOT/$out/c5dev.err
+MCMCHIP_TRACE=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/trace -o c5 --output-format csv -- python3 $GRAFT_REPO_ROOT/tests/secondary_bench.py c5dev=100000256,256,10000 > $GRAFT_REPO_ROOT/$out/c5dev.log 2> $GRAFT_REPO_ROOT/$out/c5dev.err
