@@ -5,7 +5,8 @@ C-ABI of include/mcmchip.h); this package is the thin host-side mirror of the re
 R front ends (R/metrop.R, R/morph.metrop.R, R/morph.R, R/temper.R, R/initseq.R, R/olbm.R).
 """
 _API = ("metrop", "morph_metrop", "temper", "initseq", "olbm", "logdens", "Target", "logistic_target",
-        "load_library", "library_path", "McmcHipError")
+        "load_library", "library_path", "McmcHipError", "tune_pseudo_prior", "logistic_models_target",
+        "set_interrupt_poll", "set_launch_limit")
 _MORPH = ("morph", "morph_identity", "Morph")
 
 

@@ -384,6 +384,56 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
     return out
 
 
+def logistic_models_target(x, y, models, prior_sd=2.0, log_pseudo_prior=None, normalized_prior=True, device=None):
+    """the model-selection posterior of vignettes/bfst.Rnw:472-489 (serial tempering over sub-models of a logistic
+    regression): `models` is the k x (d - 1) 0/1 matrix of which predictors enter model i (the intercept always does),
+    the prior is iid N(0, prior_sd^2) with its normalizing constant (bfst.Rnw:453-459: needed when models of different
+    dimension are compared) unless normalized_prior is False (tests/temp-par.R:39-56)"""
+    x = np.asarray(x, dtype=np.float64)
+    models = np.asarray(models)
+    masks = np.column_stack([np.ones(models.shape[0]), models]).astype(np.float64)
+    d = x.shape[1]
+    const = -d * np.log(prior_sd * np.sqrt(2.0 * np.pi)) if normalized_prior else 0.0
+    par = abi.logistic_models_par(masks, log_pseudo_prior, const)
+    return Target(abi.T_LOGISTIC_MODELS, d, x=x, y=y, prior_c=1.0 / (2.0 * prior_sd ** 2), par=par, device=device)
+
+
+def tune_pseudo_prior(x, y, models, initial, neighbors, nbatch, blen=1, nspac=1, scale=1, prior_sd=2.0,
+                      log_pseudo_prior=None, max_rounds=50, ratio=2.0, cap=10.0, seed=None):
+    """The trial-and-error loop of vignettes/bfst.Rnw:497-559 as a driver: serial tempering over the sub-models, then
+        qux <- qux + pmin(log(max(ibar) / ibar), 10);  qux <- qux - min(qux)        (bfst.Rnw:516-517, 546-547)
+    with ibar = colMeans(ibatch), continuing from the last state (544), until max(ibar) / min(ibar) < 2 (550).
+    `initial` is c(i, beta) or nens x (1 + d) (ibar then averages over the ensembles too).
+    Returns {"log.pseudo.prior", "qux.save", "ibar.save", "rounds", "out"}; the log 10 unnormalized Bayes factors of
+    bfst.Rnw:610 are (log.pseudo.prior - log(colMeans(out["ibatch"]))) / log(10)."""
+    models = np.asarray(models)
+    k = models.shape[0]
+    qux = np.zeros(k) if log_pseudo_prior is None else np.asarray(log_pseudo_prior, dtype=np.float64).copy()
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little")
+    qux_save, ibar_save = [], []
+    out = None
+    for rounds in range(1, int(max_rounds) + 1):
+        tg = logistic_models_target(x, y, models, prior_sd=prior_sd, log_pseudo_prior=qux)
+        if out is None:
+            out = temper(tg, initial, neighbors, nbatch, blen, nspac, scale, parallel=False, seed=seed)
+        else:
+            prev = dict(out)
+            prev["lud"] = tg                       # temper(out, log.pseudo.prior = qux): same stream, new pseudo-prior
+            out = temper(prev)
+        ib = np.asarray(out["ibatch"])
+        ibar = ib.reshape(-1, k).mean(axis=0)
+        ibar_save.append(ibar)
+        if ibar.min() > 0 and ibar.max() / ibar.min() < ratio:
+            break
+        with np.errstate(divide="ignore"):
+            qux = qux + np.minimum(np.log(ibar.max() / ibar), cap)
+        qux = qux - qux.min()
+        qux_save.append(qux.copy())
+    return {"log.pseudo.prior": qux, "qux.save": np.array(qux_save), "ibar.save": np.array(ibar_save),
+            "rounds": rounds, "out": out}
+
+
 def initseq(x):
     """initseq(x): R/initseq.R:1-5 -- x numeric, all finite; the series is centred here and the
     centred series goes to the native routine.  A 2-d x (len x ncol) is a batch of series and

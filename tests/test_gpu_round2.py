@@ -553,3 +553,29 @@ def test_time_based_launch_budget(api, launch_limit):
     launch_limit(0, 0.25)
     assert n_one <= 2 and n_cut > n_one
     assert np.array_equal(o["batch"], one["batch"]) and np.array_equal(o["final"], one["final"])
+
+
+# ----------------------------------------------------------------------------- pseudo-prior tuning (bfst.Rnw:497-559)
+def test_tune_pseudo_prior_flattens_occupancy(api):
+    """serial tempering over the 8 sub-models of y ~ x1 + x2 + x3 on the reference's `foo` data with the vignette's
+    normalized N(0, 2^2) prior: with log pseudo-priors zero the chain sits in a few models; the adjustment loop of
+    bfst.Rnw:516-550 must make the occupation fractions flat (max / min < 2) and its Bayes factors must agree with a
+    second, longer run at the tuned pseudo-prior"""
+    from rhelpers import temp_par_setup
+    X, y, models, masks, betas, nb = temp_par_setup()
+    E = 64
+    init = np.tile(np.concatenate([[8.0], betas[7]]), (E, 1))
+    res = api.tune_pseudo_prior(X, y, models, init, nb, nbatch=100, blen=50, scale=0.5, seed=20240612)
+    ibar0, ibar1 = res["ibar.save"][0], res["ibar.save"][-1]
+    assert ibar0.max() / max(ibar0.min(), 1e-300) > 2.0          # untuned: unbalanced (the vignette's "what happened")
+    assert res["rounds"] >= 2 and res["rounds"] <= 30
+    assert ibar1.min() > 0 and ibar1.max() / ibar1.min() < 2.0
+    assert res["log.pseudo.prior"].min() == 0.0
+    # Bayes factors (bfst.Rnw:610): stable under a longer run at the tuned pseudo-prior
+    qux = res["log.pseudo.prior"]
+    bf1 = (qux - np.log(ibar1)) / np.log(10)
+    tg = api.logistic_models_target(X, y, models, log_pseudo_prior=qux)
+    o = api.temper(tg, res["out"]["final"], nb, 400, 50, 1, 0.5, parallel=False, seed=7)
+    ibar2 = o["ibatch"].reshape(-1, 8).mean(axis=0)
+    bf2 = (qux - np.log(ibar2)) / np.log(10)
+    assert np.max(np.abs((bf1 - bf1.min()) - (bf2 - bf2.min()))) < 0.15
