@@ -195,7 +195,13 @@ enum {
      * parallel (tests/temp-par-witch.R:52-59): k values, as.numeric(all(|theta_i| > bnd_i)) per component;
      * serial (tests/temp-ser-witch.R:51-62): 2k values c(bar, baz), bar[i] = all(|theta| > bnd_i), baz[i] = 1 for
      * the current component i, zeros elsewhere */
-    MCMCHIP_TOUT_WITCH_CORNER = 1
+    MCMCHIP_TOUT_WITCH_CORNER = 1,
+    /* the index-vector and moment functionals that metrop has (metrop.c:435-497, vignettes/demo.Rnw:264), applied to
+     * the identity output v (parallel: the k*p state entries in the state's own order state[i + k*j]; serial: x):
+     * INDEX keeps v[j] where args.out_index[j] != 0, MOMENTS2 is c(v, v^2).  The reference's temper() takes an R
+     * function here (temper.c:977-988); these two cover the common ones without a closure. */
+    MCMCHIP_TOUT_INDEX = 2,
+    MCMCHIP_TOUT_MOMENTS2 = 3
 };
 /* temper kernels (args.path; AUTO = 0 picks): LDS = one wavefront per ensemble with the state in LDS (any shape,
  * serial tempering, debug trace); RUN = lane-per-component registers, runs of iterations on disjoint components
@@ -223,10 +229,12 @@ typedef struct mcmchip_temper_args {
     int32_t debug;                   /* fill the debug trace (temper.c:282-464, vignettes/debug.Rnw:64-243) */
     int32_t out_kind;                /* output functional (temper.c:977-988 evaluates an R closure): MCMCHIP_TOUT_* */
     int32_t path;                    /* MCMCHIP_PATH_AUTO, or force one kernel: MCMCHIP_PATH_LDS | MCMCHIP_PATH_RUN */
+    const int32_t *out_index;        /* MCMCHIP_TOUT_INDEX: 0/1 mask over the identity output (k*p | p entries), host memory */
 } mcmchip_temper_args;
 
 typedef struct mcmchip_temper_out {
-    double *batch;     /* out_kind != IDENTITY: nens x (nbatch x nout), per ensemble batch[kb + nbatch*j];
+    double *batch;     /* out_kind != IDENTITY: nens x (nbatch x nout), per ensemble batch[kb + nbatch*j]
+                          (nout: CORNER k | 2k, INDEX the number of kept entries, MOMENTS2 twice the identity's);
                           parallel: nens x (nbatch x k x p), per ensemble batch[kb + nbatch*(i + k*j)] (temper.c:871-875);
                           serial:   nens x (nbatch x p),     per ensemble batch[kb + nbatch*j]       (temper.c:877-879) */
     double *ibatch;    /* serial only: nens x (nbatch x k), ibatch[kb + nbatch*i] (temper.c:881-886); may be NULL if parallel */

@@ -10,7 +10,7 @@ OK, EINVAL, EDOMAIN, EHIP, ECAP, EINTR = 0, 1, 2, 3, 4, 5
 T_LOGISTIC, T_LOGISTIC_NAIVE, T_MVNORM, T_NORMMIX = 1, 2, 3, 4
 T_SIMPLEX, T_BALL, T_WITCH, T_TEMPERED_NORMMIX = 5, 6, 7, 8
 T_STUDENT_T = 9
-TOUT_IDENTITY, TOUT_WITCH_CORNER = 0, 1
+TOUT_IDENTITY, TOUT_WITCH_CORNER, TOUT_INDEX, TOUT_MOMENTS2 = 0, 1, 2, 3
 T_LOGISTIC_MODELS = 10
 T_BINOMIAL_LOGIT = 11
 TEMPER_KINDS = (T_WITCH, T_TEMPERED_NORMMIX, T_LOGISTIC_MODELS)
@@ -108,6 +108,7 @@ class TemperArgs(C.Structure):
         ("debug", C.c_int32),
         ("out_kind", C.c_int32),
         ("path", C.c_int32),
+        ("out_index", C.c_void_p),
     ]
 
 
@@ -346,7 +347,8 @@ class TemperCall:
     """numpy-backed argument/result block for one mcmchip_temper / orc_temper call"""
 
     def __init__(self, p, initial, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=RNG_PHILOX,
-                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None, debug=False, out_kind=0, path=0):
+                 unif=None, norm=None, seed=0, ens_offset=0, iter_offset=0, nout=None, debug=False, out_kind=0, path=0,
+                 out_index=None):
         nb = np.asarray(neighbors)
         if nb.ndim != 2:
             raise ValueError('argument "neighbors" must be matrix')
@@ -380,6 +382,15 @@ class TemperCall:
         self.out_kind = int(out_kind)
         if nout is None and self.out_kind == TOUT_WITCH_CORNER:
             nout = k if self.parallel else 2 * k
+        nid = k * p if self.parallel else p            # length of the identity output
+        self.out_index = None
+        if self.out_kind == TOUT_INDEX:
+            self.out_index = np.ascontiguousarray(out_index, dtype=np.int32)
+            if self.out_index.shape != (nid,):
+                raise ValueError("out_index must have one entry per element of the identity output")
+            nout = int((self.out_index != 0).sum())
+        elif self.out_kind == TOUT_MOMENTS2:
+            nout = 2 * nid
         self.identity_out = nout is None
         self.nout = nout if nout is not None else nstate - (0 if self.parallel else 1)
         self.batch = np.empty((E, self.nout, self.nbatch))       # per ensemble batch[kb + nbatch*i]
@@ -402,7 +413,8 @@ class TemperCall:
         self.args = TemperArgs(E, k, int(self.parallel), self.nbatch, self.blen, self.nspac,
                                np_ptr(self.neighbors), np_ptr(self.initial), self.scale_kind,
                                np_ptr(self.scale), int(rng_mode), np_ptr(self.unif), np_ptr(self.norm),
-                               int(seed), int(ens_offset), int(iter_offset), 0, int(self.debug), self.out_kind, int(path))
+                               int(seed), int(ens_offset), int(iter_offset), 0, int(self.debug), self.out_kind, int(path),
+                               np_ptr(self.out_index))
         self.out = TemperOut(np_ptr(self.batch), np_ptr(self.ibatch), np_ptr(self.acceptx),
                              np_ptr(self.accepti), np_ptr(self.final), 0,
                              *[np_ptr(dbg.get(n)) for n in ("which", "unif_which", "state", "log_hastings",

@@ -312,9 +312,11 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
     initial  parallel: k x p matrix (or nens x k x p); serial: c(i, x) (or nens x (1+p))
     Returns the reference's names: lud, neighbors, nbatch, blen, nspac, scale, outfun, debug,
     parallel, initial.seed, final.seed, time, batch, acceptx, accepti, initial, final [, ibatch].
-    outfun   None (identity, temper.c:851-867) or "witch.corner", the indicator functional of the reference's
-             witch's-hat tests (tests/temp-par-witch.R:52-59, temp-ser-witch.R:51-62); R closures cannot run on
-             the device.  A restart keeps the previous outfun when none is given (R/temper.R:16-18).
+    outfun   None (identity, temper.c:851-867); "witch.corner", the indicator functional of the reference's
+             witch's-hat tests (tests/temp-par-witch.R:52-59, temp-ser-witch.R:51-62); an index or logical vector
+             over the identity output (metrop's rules, metrop.c:435-497; parallel: the k x p state in R's
+             column-major order) or "moments2" = c(v, v^2); R closures cannot run on the device.  A restart keeps
+             the previous outfun when none is given (R/temper.R:16-18).
     debug = TRUE returns the reference's trace
     (which, unif.which, state, log.hastings, unif.hastings, proposal, acceptd, norm, unif.choose[, coproposal]).
     """
@@ -342,15 +344,25 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
     debug = False if debug is None else debug
     if not isinstance(target, Target) or not target.is_temper_kind:
         raise TypeError('argument "obj" must be a tempering Target or a previous result')
+    init_arr = np.asarray(initial, dtype=np.float64)
+    out_index = None
     if outfun is None:
         out_kind = abi.TOUT_IDENTITY
-    elif outfun == "witch.corner":
+    elif isinstance(outfun, str) and outfun == "witch.corner":
         out_kind = abi.TOUT_WITCH_CORNER
+    elif isinstance(outfun, str) and outfun == "moments2":
+        out_kind = abi.TOUT_MOMENTS2
     elif callable(outfun):
         raise NotImplementedError("temper: outfun functions cannot run on the device path")
-    else:
+    elif isinstance(outfun, str):
         raise ValueError('argument "outfun" must be function or NULL')          # temper.c:68-69
-    init_arr = np.asarray(initial, dtype=np.float64)
+    else:
+        # index / logical vector over the identity output (parallel: the k x p state in R's column-major order,
+        # serial: x), with metrop's rules (metrop.c:435-497)
+        k_ = np.asarray(neighbors).shape[0]
+        nid = k_ * target.d if parallel else target.d
+        kind_, mask, _ = abi.resolve_outfun(outfun, nid)
+        out_kind, out_index = abi.TOUT_INDEX, mask
     single = init_arr.ndim == (2 if parallel else 1)
     if unif is not None or norm is not None:
         mode = abi.RNG_INJECTED
@@ -360,7 +372,7 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
             seed = int.from_bytes(os.urandom(8), "little")
     call = abi.TemperCall(target.d, init_arr, neighbors, nbatch, blen, nspac, scale, parallel, rng_mode=mode,
                           unif=unif, norm=norm, seed=seed or 0, ens_offset=ens_offset,
-                          iter_offset=_iter_offset, debug=debug, out_kind=out_kind, path=_path)
+                          iter_offset=_iter_offset, debug=debug, out_kind=out_kind, path=_path, out_index=out_index)
     t0 = time.perf_counter()
     _check(load_library().mcmchip_temper(target.handle, C.addressof(call.args), C.addressof(call.out)))
     elapsed = time.perf_counter() - t0

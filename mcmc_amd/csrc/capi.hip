@@ -618,14 +618,31 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
 
     hipStream_t s = dc->stream;
     const int dp = a->device_ptrs;
-    if (a->out_kind != MCMCHIP_TOUT_IDENTITY && a->out_kind != MCMCHIP_TOUT_WITCH_CORNER)
+    if (a->out_kind < MCMCHIP_TOUT_IDENTITY || a->out_kind > MCMCHIP_TOUT_MOMENTS2)
         return set_error(MCMCHIP_EINVAL, "argument \"outfun\" must be function or NULL");     // temper.c:68-69
+    // index vector / moments over the identity output v (k*p state entries, or x): g_i = v[map[i]] (^2 from sq_from on)
+    std::vector<int> tmap;
+    int tsq_from = 0;
+    {
+        const int nid = a->parallel ? k * p : p;
+        if (a->out_kind == MCMCHIP_TOUT_INDEX) {
+            if (!a->out_index) return set_error(MCMCHIP_EINVAL, "outfun index vector missing");
+            for (int j = 0; j < nid; j++) if (a->out_index[j]) tmap.push_back(j);
+            tsq_from = (int)tmap.size();
+        } else if (a->out_kind == MCMCHIP_TOUT_MOMENTS2) {
+            for (int j = 0; j < 2 * nid; j++) tmap.push_back(j % nid);
+            tsq_from = nid;
+        }
+    }
     if (a->out_kind == MCMCHIP_TOUT_WITCH_CORNER && t->kind != MCMCHIP_T_WITCH)
         return set_error(MCMCHIP_EINVAL, "the corner-indicator output functional belongs to the witch's hat descriptor");
     if (a->path != MCMCHIP_PATH_AUTO && a->path != MCMCHIP_PATH_LDS && a->path != MCMCHIP_PATH_RUN)
         return set_error(MCMCHIP_EINVAL, "unknown temper path %d", a->path);
-    const int nout = a->out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (a->parallel ? k : 2 * k) : (a->parallel ? k * p : p);
-    InBuf init, scale, nbrs, unif, norm;
+    const bool tmapped = a->out_kind == MCMCHIP_TOUT_INDEX || a->out_kind == MCMCHIP_TOUT_MOMENTS2;
+    const int nout = tmapped ? (int)tmap.size()
+                             : (a->out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (a->parallel ? k : 2 * k) : (a->parallel ? k * p : p));
+    InBuf init, scale, nbrs, unif, norm, tmapbuf;
+    if (tmapped && !tmap.empty()) HIP_TRY(tmapbuf.set(tmap.data(), tmap.size() * sizeof(int), 0, s));
     OutBuf batch, ibatch, acceptx, accepti, final_;
     HIP_TRY(init.set(a->initial, (size_t)nens * nstate * 8, dp, s));
     HIP_TRY(scale.set(a->scale, slen * 8, 0, s));
@@ -668,6 +685,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     q.accepti = accepti.as<double>(); q.final_ = final_.as<double>();
     q.debug = a->debug;
     q.out_kind = a->out_kind;
+    q.out_map = tmapbuf.as<int>(); q.nout_map = (int)tmap.size(); q.sq_from = tsq_from;
     q.path = a->path;
     q.dbg_which = dwhich.as<int>(); q.dbg_acceptd = dacc.as<int>(); q.dbg_unif_which = duw.as<double>();
     q.dbg_state = dstate.as<double>(); q.dbg_lh = dlh.as<double>(); q.dbg_uh = duh.as<double>();

@@ -75,6 +75,9 @@ struct TemperDev {
     double *batch, *ibatch, *acceptx, *accepti, *final_;
     int debug;
     int out_kind;             // MCMCHIP_TOUT_*
+    // MCMCHIP_TOUT_INDEX / _MOMENTS2: g_i = v[out_map[i]] (squared when i >= sq_from), v the identity output
+    const int *out_map;
+    int nout_map, sq_from;
     int path;                 // MCMCHIP_PATH_AUTO | _LDS | _RUN
     // one launch: iterations [it_begin, it_end) (multiples of 64 except the end of the run); resume = 1 restores the
     // ensemble's record from `carry`

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
     const int k = q.k, p = q.p, par = q.parallel;
     const int nstate = par ? k * p : p + 1;
     const int corner = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER;
-    const int nout = corner ? (par ? k : 2 * k) : (par ? k * p : p);
+    const bool mapped = q.out_kind == MCMCHIP_TOUT_INDEX || q.out_kind == MCMCHIP_TOUT_MOMENTS2;
+    const int nout = mapped ? q.nout_map : (corner ? (par ? k : 2 * k) : (par ? k * p : p));
     double *S = lds + lay.state, *L = lds + lay.L, *Y = lds + lay.Y, *Z = lds + lay.Z;
     double *buf = lds + lay.buf, *ibuf = lds + lay.ibuf;
     unsigned *axn = (unsigned *)(lds + lay.axn), *axd = (unsigned *)(lds + lay.axd);
@@ -318,7 +319,13 @@ __global__ __launch_bounds__(64) void temper_kernel(TemperDev q, TemperLds lay, 
             if (++is < q.nspac) continue;
             is = 0;
             // batch accumulation once per blen step (temper.c:851-867)
-            if (!corner) {
+            if (mapped) {                       // index vector / c(v, v^2) over the identity output
+                for (int i = lane; i < nout; i += 64) {
+                    double v = S[q.out_map[i] + (par ? 0 : 1)];
+                    if (i >= q.sq_from) v = mul_nofma(v, v);
+                    buf[i] = add_nofma(buf[i], v);
+                }
+            } else if (!corner) {
                 for (int i = lane; i < nout; i += 64) buf[i] += par ? S[i] : S[i + 1];
             } else if (par) {                   // tests/temp-par-witch.R:52-59
                 for (int i = lane; i < k; i += 64) {
@@ -796,6 +803,13 @@ static int launch_temper_run(const TemperDev &q, int maxnn, hipStream_t s)
     return MCMCHIP_OK;
 }
 
+static int temper_nout(const TemperDev &q)
+{
+    if (q.out_kind == MCMCHIP_TOUT_INDEX || q.out_kind == MCMCHIP_TOUT_MOMENTS2) return q.nout_map;
+    if (q.out_kind == MCMCHIP_TOUT_WITCH_CORNER) return q.parallel ? q.k : 2 * q.k;
+    return q.parallel ? q.k * q.p : q.p;
+}
+
 // one launch of the chosen kernel over q.it_begin .. q.it_end
 static int launch_temper_once(const TemperDev &q, bool run_kernel, hipStream_t s, size_t *carry_doubles)
 {
@@ -810,7 +824,7 @@ static int launch_temper_once(const TemperDev &q, bool run_kernel, hipStream_t s
         return set_error(MCMCHIP_EINVAL, "run-parallel tempering path: bad dimension %d", p);
     }
     const int nstate = q.parallel ? k * p : p + 1;
-    const int nout = q.out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (q.parallel ? k : 2 * k) : (q.parallel ? k * p : p);
+    const int nout = temper_nout(q);
     TemperLds lay;
     int o = 0;
     lay.state = o; o += nstate;
@@ -857,10 +871,11 @@ int launch_temper(const TemperDev &q0, hipStream_t s)
     // run-parallel kernel for the common parallel-tempering shape (faster than temper_kernel from k = 4 up, measured);
     // everything else takes temper_kernel
     const bool run_ok = q.parallel && !q.debug && k <= 64 && p >= 1 && p <= 4 && maxnn <= 8 &&
+                        (q.out_kind == MCMCHIP_TOUT_IDENTITY || q.out_kind == MCMCHIP_TOUT_WITCH_CORNER) &&
                         (q.kind == MCMCHIP_T_WITCH || q.kind == MCMCHIP_T_TEMPERED_NORMMIX);
     if (q.path == MCMCHIP_PATH_RUN && !run_ok)
         return set_error(MCMCHIP_EINVAL, "run-parallel tempering path needs parallel = 1, debug = 0, k <= 64, p <= 4, "
-                                         "at most 8 neighbours per component and a closed-form descriptor");
+                                         "at most 8 neighbours per component, a closed-form descriptor and the identity or corner output");
     const bool run_kernel = run_ok && q.path != MCMCHIP_PATH_LDS;
     // The run as a sequence of launches (temper.c:848 polls for an interrupt every iteration; here the host does between
     // launches): a short calibration launch, then about a quarter of a second each, cut at multiples of 64 iterations.
@@ -879,7 +894,7 @@ int launch_temper(const TemperDev &q0, hipStream_t s)
             // size of an ensemble's carry record: ask the launcher (same formula it uses) without launching
             cd = run_kernel ? (size_t)64 * (2 * p + 3) + 2 * (size_t)k * maxnn
                             : (size_t)((q.parallel ? k * p : p + 1) + k + 2 * p +
-                                       (q.out_kind == MCMCHIP_TOUT_WITCH_CORNER ? (q.parallel ? k : 2 * k) : (q.parallel ? k * p : p)) + k +
+                                       temper_nout(q) + k +
                                        2 * ((k + 1) / 2) + 3 * ((k * maxnn + 1) / 2) + (k + 1) / 2);
             HIP_TRY(carry.alloc((size_t)q.nens * cd * 8));
             qq.carry = carry.as<double>();

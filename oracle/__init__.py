@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 RNG_RSTREAM = 3
-TOUT_NONE, TOUT_WITCH_PAR, TOUT_WITCH_SER = 0, 1, 2
+TOUT_NONE, TOUT_WITCH_PAR, TOUT_WITCH_SER, TOUT_INDEX, TOUT_MOMENTS2 = 0, 1, 2, 3, 4
 
 
 def build(force=False):
@@ -180,7 +180,7 @@ def metrop(target, initial, nbatch, blen=1, nspac=1, scale=1.0, outfun=None, deb
 
 def temper(target, initial, neighbors, nbatch, blen=1, nspac=1, scale=1.0, parallel=False,
            rstream=None, unif=None, norm=None, seed=None, ens_offset=0, iter_offset=0,
-           out_kind=TOUT_NONE, nthreads=1, debug=False):
+           out_kind=TOUT_NONE, nthreads=1, debug=False, out_index=None):
     if rstream is not None:
         mode = RNG_RSTREAM
     elif unif is not None:
@@ -188,10 +188,12 @@ def temper(target, initial, neighbors, nbatch, blen=1, nspac=1, scale=1.0, paral
     else:
         mode = abi.RNG_PHILOX
     k = np.asarray(neighbors).shape[0]
-    nout = {TOUT_NONE: None, TOUT_WITCH_PAR: k, TOUT_WITCH_SER: 2 * k}[out_kind]
+    nout = {TOUT_NONE: None, TOUT_WITCH_PAR: k, TOUT_WITCH_SER: 2 * k, TOUT_INDEX: None, TOUT_MOMENTS2: None}[out_kind]
+    abi_kind = {TOUT_INDEX: abi.TOUT_INDEX, TOUT_MOMENTS2: abi.TOUT_MOMENTS2}.get(out_kind, 0)
     call = abi.TemperCall(target.d, initial, neighbors, nbatch, blen, nspac, scale, parallel,
                           rng_mode=abi.RNG_PHILOX, unif=unif, norm=norm, seed=seed or 0,
-                          ens_offset=ens_offset, iter_offset=iter_offset, nout=nout, debug=debug)
+                          ens_offset=ens_offset, iter_offset=iter_offset, nout=nout, debug=debug,
+                          out_kind=abi_kind, out_index=out_index)
     call.args.rng_mode = mode
     err = C.create_string_buffer(256)
     rc = lib().orc_temper(C.addressof(target.desc), C.addressof(call.args), C.addressof(call.out),

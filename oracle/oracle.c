@@ -629,6 +629,13 @@ static int t_nout(const mcmchip_target_desc *t, const mcmchip_temper_args *a, in
     case ORC_TOUT_NONE: return a->parallel ? k * p : p;
     case ORC_TOUT_WITCH_PAR: return k;       /* temp-par-witch.R: as.numeric(all(|theta_i| > bnd_i)) per component */
     case ORC_TOUT_WITCH_SER: return 2 * k;   /* temp-ser-witch.R: c(bar, baz) */
+    case ORC_TOUT_INDEX: {
+        int nid = a->parallel ? k * p : p, n = 0;
+        if (!a->out_index) return -1;
+        for (int j = 0; j < nid; j++) n += a->out_index[j] != 0;
+        return n;
+    }
+    case ORC_TOUT_MOMENTS2: return 2 * (a->parallel ? k * p : p);
     default: return -1;
     }
 }
@@ -640,6 +647,14 @@ static void t_out(const mcmchip_target_desc *t, const mcmchip_temper_args *a, in
     if (out_kind == ORC_TOUT_NONE) {
         if (a->parallel) for (int i = 0; i < k * p; i++) g[i] = state[i];
         else for (int i = 0; i < p; i++) g[i] = state[i + 1];
+    } else if (out_kind == ORC_TOUT_INDEX || out_kind == ORC_TOUT_MOMENTS2) {
+        int nid = a->parallel ? k * p : p, n = 0;
+        const double *v = a->parallel ? state : state + 1;
+        if (out_kind == ORC_TOUT_INDEX) {
+            for (int j = 0; j < nid; j++) if (a->out_index[j]) g[n++] = v[j];
+        } else {
+            for (int j = 0; j < nid; j++) { g[j] = v[j]; g[nid + j] = v[j] * v[j]; }
+        }
     } else if (out_kind == ORC_TOUT_WITCH_PAR) {
         for (int i = 0; i < k; i++) {
             int all = 1;

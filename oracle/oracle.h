@@ -15,6 +15,8 @@ extern "C" {
 #define ORC_TOUT_NONE 0
 #define ORC_TOUT_WITCH_PAR 1
 #define ORC_TOUT_WITCH_SER 2
+#define ORC_TOUT_INDEX 3      /* a->out_index mask over the identity output */
+#define ORC_TOUT_MOMENTS2 4   /* c(v, v^2) of the identity output */
 
 typedef struct orc_rstream orc_rstream;
 orc_rstream *orc_r_new(int kind /*0 Mersenne-Twister, 1 Marsaglia-Multicarry*/, uint32_t seed);

@@ -579,3 +579,41 @@ def test_tune_pseudo_prior_flattens_occupancy(api):
     ibar2 = o["ibatch"].reshape(-1, 8).mean(axis=0)
     bf2 = (qux - np.log(ibar2)) / np.log(10)
     assert np.max(np.abs((bf1 - bf1.min()) - (bf2 - bf2.min()))) < 0.15
+
+
+# ----------------------------------------------------------------------------- temper output functionals
+@pytest.mark.parametrize("parallel", [True, False])
+@pytest.mark.parametrize("outfun", ["moments2", "index", "negindex", "logical"])
+def test_temper_index_and_moment_outfuns(api, oracle_mod, parallel, outfun):
+    """index-vector and c(v, v^2) output functionals for temper (metrop's rules, metrop.c:435-497, applied to the
+    identity output of temper.c:851-864) against the oracle, and against the identity run they are functions of"""
+    rng = np.random.default_rng(17)
+    k, p, E, nbatch, blen, nspac = 5, 2, 7, 8, 4, 3
+    niter = nbatch * blen * nspac
+    betas = np.geomspace(1.0, 0.1, k)
+    par = np.concatenate([[float(k)], betas, abi.normmix_par([0.5, 0.5], [[-2.0, -2.0], [2.0, 2.0]], 1.0)])
+    nb = np.abs(np.subtract.outer(np.arange(k), np.arange(k))) == 1
+    nid = k * p if parallel else p
+    of = {"moments2": "moments2", "index": [1, nid], "negindex": [-1], "logical": (np.arange(nid) % 2 == 0)}[outfun]
+    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+    init = np.tile([2.0, 2.0], (E, k, 1)) if parallel else np.column_stack([rng.integers(1, k + 1, E).astype(float), np.tile([2.0, 2.0], (E, 1))])
+    tg, otg = api.Target(abi.T_TEMPERED_NORMMIX, p, par=par), oracle_mod.Target(abi.T_TEMPERED_NORMMIX, p, par=par)
+    o = api.temper(tg, init, nb, nbatch, blen, nspac, 0.7, parallel=parallel, unif=unif, norm=norm, outfun=of)
+    ident = api.temper(tg, init, nb, nbatch, blen, nspac, 0.7, parallel=parallel, unif=unif, norm=norm)
+    kind, mask, nout = abi.resolve_outfun(of, nid)
+    okind = oracle_mod.TOUT_MOMENTS2 if outfun == "moments2" else oracle_mod.TOUT_INDEX
+    ref = oracle_mod.temper(otg, init, nb, nbatch, blen, nspac, 0.7, parallel=parallel, unif=unif, norm=norm,
+                            out_kind=okind, out_index=mask)
+    assert o["batch"].shape == (E, nbatch, nout) == ref["batch"].shape
+    assert np.array_equal(o["final"], ref["final"]) and np.array_equal(o["final"], ident["final"])
+    assert rel(o["batch"] + 10, ref["batch"] + 10) < RTOL
+    # the identity output in the state's own (column-major) order
+    v = ident["batch"].transpose(0, 1, 3, 2).reshape(E, nbatch, nid) if parallel else ident["batch"]
+    if outfun == "moments2":
+        assert np.array_equal(o["batch"][:, :, :nid], v)
+        assert np.all(o["batch"][:, :, nid:] >= v ** 2 - 1e-12)            # mean of squares >= square of mean
+    else:
+        assert np.array_equal(o["batch"], v[:, :, mask.astype(bool)])
+    # a restart keeps the functional (R/temper.R:22-30)
+    o2 = api.temper(o, unif=unif, norm=norm)
+    assert o2["batch"].shape == o["batch"].shape
