@@ -299,6 +299,17 @@ int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs,
                     double *gamma0, double *Gamma_pos, double *Gamma_dec, double *Gamma_con,
                     double *var_pos, double *var_dec, double *var_con);
 
+/* The two halves of initseq for a series sharded BY TIME over several GPUs (no counterpart in the
+ * single-process reference): the raw lag sums  sums[c * nlags + l] = sum_t x[t + len*c] * x[t + l + len*c]  over the
+ * whole array given (terms past its end are zero), l = 0 .. nlags-1, which add up over shards (a shard owning rows
+ * [lo, hi) holds a halo of nlags rows and subtracts the sums of the halo alone, mcmc_amd/dist.py), and the stop rule
+ * plus the three sequences (initseq.c:24-105) applied to the TOTAL sums of a series of length `len`.  The second is
+ * host-only.  n_out[c] = -1: column c has not reached its stopping lag within nlags, come back with more. */
+int mcmchip_lagsums(const double *x, int64_t len, int64_t ncol, int64_t nlags, int device_ptrs, double *sums /* host */);
+int mcmchip_initseq_from_lagsums(const double *sums, int64_t len, int64_t ncol, int64_t nlags, int64_t cap, int64_t *n_out,
+                                 double *gamma0, double *Gamma_pos, double *Gamma_dec, double *Gamma_con,
+                                 double *var_pos, double *var_dec, double *var_con);
+
 /* olbm -- replaces void olbm(double *x, int *nin, int *pin, int *lin, double *mean,
  * double *var, int *nocalcin) (mcmc.h:16-17, olbm.c:22-78).  x is n x p column-major.
  * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned. */

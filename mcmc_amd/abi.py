@@ -145,6 +145,8 @@ EXPORTS = [
     "mcmchip_metrop",
     "mcmchip_temper",
     "mcmchip_initseq",
+    "mcmchip_lagsums",
+    "mcmchip_initseq_from_lagsums",
     "mcmchip_olbm",
     "mcmchip_set_interrupt_poll",
     "mcmchip_set_launch_limit",

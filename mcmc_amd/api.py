@@ -60,6 +60,10 @@ def load_library():
     L.mcmchip_temper.restype = C.c_int
     L.mcmchip_initseq.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64] + [C.c_void_p] * 8
     L.mcmchip_initseq.restype = C.c_int
+    L.mcmchip_lagsums.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+    L.mcmchip_lagsums.restype = C.c_int
+    L.mcmchip_initseq_from_lagsums.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 8
+    L.mcmchip_initseq_from_lagsums.restype = C.c_int
     L.mcmchip_olbm.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_int]
     L.mcmchip_olbm.restype = C.c_int
@@ -481,6 +485,67 @@ def initseq(x):
         res.append({"gamma0": g0[c], "Gamma.pos": Gp[c, :m].copy(), "Gamma.dec": Gd[c, :m].copy(),
                     "Gamma.con": Gc[c, :m].copy(), "var.pos": vp[c], "var.dec": vd[c], "var.con": vc[c]})
     return res[0] if single else res
+
+
+def _colmajor(x):
+    """(pointer, len, ncol, device_ptrs, keepalive) of a batch of series for the C-ABI's column-major layout x[t + len*c].
+    numpy: len x ncol (or a vector), copied into column-major order.  torch CUDA tensor: ncol x len contiguous (already
+    column-major from R's point of view), used in place -- nothing crosses PCIe."""
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
+        if not x.is_cuda or x.dim() != 2 or not x.is_contiguous() or str(x.dtype) != "torch.float64":
+            raise ValueError("device series must be a contiguous float64 CUDA tensor of shape (ncol, len)")
+        return x.data_ptr(), int(x.shape[1]), int(x.shape[0]), 1, x
+    a = np.asarray(x, dtype=np.float64)
+    if a.ndim == 1:
+        a = a[:, None]
+    xc = np.ascontiguousarray(a.T)
+    return xc.ctypes.data, a.shape[0], a.shape[1], 0, xc
+
+
+def lagsums(x, nlags):
+    """raw lag sums sum_t x[t] x[t + l], l < nlags, per column (ncol x nlags): the additive half of initseq, for series
+    sharded by time (mcmc_amd.dist.initseq_time_sharded).  x as for `_colmajor`; used as given (the caller centres)."""
+    init()
+    ptr, length, ncol, dp, keep = _colmajor(x)
+    out = np.empty((ncol, int(nlags)))
+    _check(load_library().mcmchip_lagsums(ptr, length, ncol, int(nlags), dp, out.ctypes.data))
+    return out
+
+
+def initseq_from_lagsums(sums, length):
+    """the stop rule and the three sequences of initseq (initseq.c:24-105) from TOTAL lag sums (ncol x nlags) of a
+    series of `length` elements; host only.  Returns a list of result dicts; None for a column whose stopping lag lies
+    beyond the lags given."""
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    ncol, nlags = sums.shape
+    cap = max(nlags // 2, 1)
+    n_out = np.zeros(ncol, dtype=np.int64)
+    g0, vp, vd, vc = (np.empty(ncol) for _ in range(4))
+    Gp, Gd, Gc = (np.empty((ncol, cap)) for _ in range(3))
+    _check(load_library().mcmchip_initseq_from_lagsums(sums.ctypes.data, int(length), ncol, nlags, cap, n_out.ctypes.data,
+                                                       g0.ctypes.data, Gp.ctypes.data, Gd.ctypes.data, Gc.ctypes.data,
+                                                       vp.ctypes.data, vd.ctypes.data, vc.ctypes.data))
+    res = []
+    for c in range(ncol):
+        m = int(n_out[c])
+        res.append(None if m < 0 else
+                   {"gamma0": g0[c], "Gamma.pos": Gp[c, :m].copy(), "Gamma.dec": Gd[c, :m].copy(),
+                    "Gamma.con": Gc[c, :m].copy(), "var.pos": vp[c], "var.dec": vd[c], "var.con": vc[c]})
+    return res
+
+
+def olbm_device(x, batch_length, mean=None):
+    """mcmchip_olbm on a series that is already in HBM: x is a contiguous float64 CUDA tensor of shape (p, n) (column-major
+    n x p); mean given -> the no.calc.mean = TRUE contract (olbm.c:37-43).  Returns (var, mean) as numpy arrays."""
+    init()
+    ptr, n, p, dp, keep = _colmajor(x)
+    if int(batch_length) > n:
+        raise ValueError("batch.length must be <= nrow(x)")
+    nocalc = mean is not None
+    m = np.zeros(p) if mean is None else np.ascontiguousarray(mean, dtype=np.float64).copy()
+    var = np.empty((p, p))
+    _check(load_library().mcmchip_olbm(ptr, n, p, int(batch_length), m.ctypes.data, var.ctypes.data, int(nocalc), dp))
+    return var, m
 
 
 def olbm(x, batch_length, demean=True, mean=None):

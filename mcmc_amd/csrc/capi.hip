@@ -734,6 +734,29 @@ int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs,
                        Gamma_con, var_pos, var_dec, var_con, dc);
 }
 
+int mcmchip_lagsums(const double *x, int64_t len, int64_t ncol, int64_t nlags, int device_ptrs, double *sums)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!x || !sums || len <= 0 || ncol <= 0 || nlags <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_lagsums");
+    InBuf in;
+    HIP_TRY(in.set(x, (size_t)len * ncol * 8, device_ptrs, dc->stream));
+    return run_lagsums(in.as<double>(), len, ncol, nlags, sums, dc);
+}
+
+int mcmchip_initseq_from_lagsums(const double *sums, int64_t len, int64_t ncol, int64_t nlags, int64_t cap, int64_t *n_out,
+                                 double *gamma0, double *Gamma_pos, double *Gamma_dec, double *Gamma_con,
+                                 double *var_pos, double *var_dec, double *var_con)
+{
+    clear_error();                   // host only: no device is touched
+    if (!sums || len <= 0 || ncol <= 0 || nlags <= 0 || cap <= 0 || !n_out || !gamma0 || !Gamma_pos || !Gamma_dec ||
+        !Gamma_con || !var_pos || !var_dec || !var_con)
+        return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_initseq_from_lagsums");
+    return run_initseq_from_lagsums(sums, len, ncol, nlags, cap, (long *)n_out, gamma0, Gamma_pos, Gamma_dec, Gamma_con,
+                                    var_pos, var_dec, var_con);
+}
+
 int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
                  int32_t nocalc, int device_ptrs)
 {

@@ -556,6 +556,62 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
     return MCMCHIP_OK;
 }
 
+// raw lag sums sum_t x[t] x[t + l], l = 0 .. nlags-1, of every column over the whole array given (zero beyond its end):
+// what a time-sharded initseq all-reduces (mcmc_amd/dist.py::initseq_time_sharded)
+int run_lagsums(const double *x, long len, long ncol, long nlags, double *sums, DeviceCtx *dc)
+{
+    const long span = (long)IS_TILE * IS_TILES_PER_BLOCK;
+    const long nblk = (len + 16 + span - 1) / span;
+    if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
+    const long units = (nlags + IS_B - 1) / IS_B;
+    LagBuffers bufs;
+    LagRound work;
+    std::vector<long> first((size_t)ncol);
+    for (long c = 0; c < ncol; c++) {
+        first[(size_t)c] = (long)work.unit_col.size();
+        work.add((int)c, 0, units);
+    }
+    std::vector<double> host;
+    timing_reset("autocov_kernel");
+    if (int rc = run_lag_round(x, len, nblk, work, bufs, host, dc)) return rc;
+    for (long c = 0; c < ncol; c++)
+        for (long l = 0; l < nlags; l++) sums[(size_t)c * nlags + l] = host[(size_t)first[(size_t)c] * IS_B + l];
+    return MCMCHIP_OK;
+}
+
+// the stop rule and the three sequences from TOTAL lag sums (host only; initseq.c:24-105 on sums computed elsewhere).
+// n_out[c] = -1 when column c has not reached its stopping lag within nlags: the caller comes back with more lags.
+int run_initseq_from_lagsums(const double *sums, long len, long ncol, long nlags, long cap, long *n_out, double *gamma0,
+                             double *Gpos, double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon)
+{
+    const long half = len / 2;
+    bool overflow = false;
+    std::vector<double> G;
+    for (long c = 0; c < ncol; c++) {
+        const double *g = sums + (size_t)c * nlags;
+        G.clear();
+        long m = -1;
+        double g0 = 0.0;
+        if (half == 0) m = 0;
+        for (long i = 0; m < 0 && 2 * i + 1 < nlags; i++) {
+            if (i >= half) { m = half; break; }
+            const double gam1 = g[2 * i] / len, gam2 = g[2 * i + 1] / len;        // initseq.c:30,39
+            if (i == 0) g0 = gam1;
+            const double Gi = gam1 + gam2;
+            if (Gi < 0.0) { G.push_back(0.0); m = i + 1; }                        // initseq.c:42-46
+            else { G.push_back(Gi); if (i + 1 >= half) m = half; }
+        }
+        gamma0[c] = nlags > 0 ? g[0] / len : 0.0;
+        n_out[c] = m;
+        if (m < 0) continue;
+        if (m > cap) { overflow = true; continue; }
+        gamma_sequences(G.data(), m, g0, GammaOut{Gpos + (size_t)c * cap, Gdec + (size_t)c * cap, Gcon + (size_t)c * cap,
+                                                   vpos + c, vdec + c, vcon + c});
+    }
+    if (overflow) return set_error(MCMCHIP_ECAP, "initseq: output capacity too small; required lengths are in n_out");
+    return MCMCHIP_OK;
+}
+
 // =============================================================================================
 // olbm
 // =============================================================================================

@@ -144,22 +144,32 @@ def olbm_time_shard(n, batch_length, rank, world_size):
     return w_lo, row_hi, own
 
 
+def _is_device_tensor(x):
+    return hasattr(x, "is_cuda") and x.is_cuda
+
+
 def olbm_sharded(olbm_local, x_local, n, batch_length, group=None, device=None):
     """olbm by time (SURVEY.md 8(e), row olbm): every rank holds rows olbm_time_shard(...) of the series.
     Two exchange steps, both tiny: an all-reduce of the column sums (p doubles) for the global means, and an
     all-reduce of the un-normalised p x p sum of outer products.  olbm_local(x, len, mean) must return the
     `nocalc` result of mcmc_amd.olbm's entry point for that block (var normalised by the block's own
-    nbatch * n * len, olbm.c:28,74), which is undone here before the reduction."""
+    nbatch * n * len, olbm.c:28,74), which is undone here before the reduction.
+    x_local: numpy rows x p, or -- the device route, nothing through host memory but p and p x p doubles -- a
+    contiguous float64 CUDA tensor of shape (p, rows) (column-major); olbm_local then receives that tensor
+    (mcmc_amd.api.olbm_device takes it)."""
     import torch.distributed as dist
 
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
-    x_local = np.asarray(x_local, dtype=np.float64)
     lo, hi, own = olbm_time_shard(n, batch_length, rank, ws)
-    if x_local.shape[0] != hi - lo:
+    on_device = _is_device_tensor(x_local)
+    if not on_device:
+        x_local = np.asarray(x_local, dtype=np.float64)
+    rows, p = (x_local.shape[1], x_local.shape[0]) if on_device else x_local.shape
+    if rows != hi - lo:
         raise ValueError("rank %d must hold rows [%d, %d) of the series" % (rank, lo, hi))
-    p = x_local.shape[1]
-    mean = all_reduce_sum(x_local[:own].sum(axis=0), group, device) / float(n)
+    colsum = x_local[:, :own].sum(dim=1).cpu().numpy() if on_device else x_local[:own].sum(axis=0)
+    mean = all_reduce_sum(colsum, group, device) / float(n)
     n_loc = hi - lo
     nwin_loc = n_loc - int(batch_length) + 1
     if nwin_loc > 0:
@@ -170,3 +180,56 @@ def olbm_sharded(olbm_local, x_local, n, batch_length, group=None, device=None):
     total = all_reduce_sum(part, group, device)
     nwin = int(n) - int(batch_length) + 1
     return total / (float(nwin) * float(n) * float(batch_length)), mean
+
+
+def initseq_time_shard(n, halo, rank, world_size):
+    """rows [row_lo, row_hi) of the series that rank `rank` holds for a time-sharded initseq: its own block of base
+    positions plus a halo of `halo` rows (the largest lag it can serve); returns (row_lo, row_hi, own)"""
+    lo, hi = shard_range(int(n), rank, world_size)
+    return lo, min(hi + int(halo), int(n)), hi - lo
+
+
+def initseq_time_sharded(lagsums, finish, x_local, n, halo, group=None, device=None, first_lags=64):
+    """initseq by time (SURVEY.md 8(e), row initseq, second way): rank r holds rows initseq_time_shard(n, halo, r, ws) of
+    the series (numpy rows x ncol, or a float64 CUDA tensor (ncol, rows) for the device route).
+    Exchange: an all-reduce of the column sums (centring, R/initseq.R:4), then per round an all-reduce of the raw lag
+    sums (ncol x nlags doubles).  A rank's share of a lag sum is over ITS base positions: the sums of its whole block
+    minus the sums of the halo alone (the halo's base positions belong to the next rank).  Rounds quadruple the lags
+    until every column has reached its stopping lag (initseq.c:42-46); a stopping lag beyond the halo is an error.
+    lagsums(x, nlags) -> ncol x nlags and finish(total_sums, n) -> list of result dicts (None: not stopped yet) are
+    mcmc_amd.api.lagsums / initseq_from_lagsums in production."""
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi, own = initseq_time_shard(n, halo, rank, ws)
+    on_device = _is_device_tensor(x_local)
+    if not on_device:
+        x_local = np.asarray(x_local, dtype=np.float64)
+    rows = x_local.shape[1] if on_device else x_local.shape[0]
+    if rows != hi - lo:
+        raise ValueError("rank %d must hold rows [%d, %d) of the series" % (rank, lo, hi))
+    colsum = x_local[:, :own].sum(dim=1).cpu().numpy() if on_device else x_local[:own].sum(axis=0)
+    mean = all_reduce_sum(colsum, group, device) / float(n)
+    if on_device:
+        import torch
+        xc = (x_local - torch.from_numpy(mean).to(x_local.device)[:, None]).contiguous()
+        tail = xc[:, own:].contiguous()
+    else:
+        xc = x_local - mean
+        tail = xc[own:]
+    nl = int(first_lags)
+    while True:
+        nl_eff = min(nl, int(n))
+        part = np.asarray(lagsums(xc, nl_eff))
+        if rows > own:                                   # the halo's own base positions belong to the next rank
+            part = part - np.asarray(lagsums(tail, nl_eff))
+        total = all_reduce_sum(part, group, device)
+        res = finish(total, int(n))
+        if all(r is not None for r in res):
+            return res
+        if nl_eff >= int(n):
+            raise RuntimeError("initseq_time_sharded: no stopping lag within the series length")
+        if nl >= int(halo) and ws > 1:
+            raise RuntimeError("initseq_time_sharded: stopping lag beyond the halo of %d rows" % int(halo))
+        nl = min(4 * nl, int(halo)) if ws > 1 else 4 * nl

@@ -617,3 +617,63 @@ def test_temper_index_and_moment_outfuns(api, oracle_mod, parallel, outfun):
     # a restart keeps the functional (R/temper.R:22-30)
     o2 = api.temper(o, unif=unif, norm=norm)
     assert o2["batch"].shape == o["batch"].shape
+
+
+# ----------------------------------------------------------------------------- multi-GPU drivers on device-resident data
+def test_time_sharded_initseq_and_olbm_device_route(api, oracle_mod):
+    """mcmc_amd/dist.py with device-resident shards (CUDA tensors, nothing but p and p x p / ncol x nlags doubles on the
+    host): ranks emulated in turn without a process group, the all-reduce replaced by a sum over the emulated ranks.
+    initseq sharded by time (raw lag sums of the block minus those of its halo) and olbm sharded by time, against the
+    oracle on the whole series."""
+    import torch
+    from mcmc_amd import dist as mdist
+    from scipy.signal import lfilter
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    n, ws, halo = 200_000, 3, 2048
+    x = np.column_stack([lfilter([1.0], [1.0, -rho], rng.standard_normal(n)) for rho in (0.3, 0.8, 0.95)]) + 0.7
+    p = x.shape[1]
+    mean = x.mean(axis=0)
+    # ---- initseq: what each emulated rank contributes per round
+    nl, total = 64, None
+    while True:
+        total = np.zeros((p, nl))
+        for r in range(ws):
+            lo, hi, own = mdist.initseq_time_shard(n, halo, r, ws)
+            blk = torch.from_numpy(np.ascontiguousarray((x[lo:hi] - mean).T)).to(dev)        # (ncol, rows), centred
+            part = api.lagsums(blk, nl)
+            if hi - lo > own:
+                part = part - api.lagsums(blk[:, own:].contiguous(), nl)
+            total += part
+        res = api.initseq_from_lagsums(total, n)
+        if all(r_ is not None for r_ in res):
+            break
+        nl *= 4
+        assert nl <= halo
+    for c in range(p):
+        ref = oracle_mod.initseq(x[:, c] - mean[c])
+        assert len(res[c]["Gamma.pos"]) == len(ref["Gamma.pos"])
+        for key in ("gamma0", "Gamma.pos", "Gamma.dec", "Gamma.con", "var.pos", "var.dec", "var.con"):
+            assert np.max(np.abs(np.asarray(res[c][key]) - np.asarray(ref[key]))) <= 1e-10 * np.max(np.abs(ref[key])), (c, key)
+    # the single-GPU entry point gives the same numbers (raw sums are the same kernel)
+    whole = api.initseq(x)
+    for c in range(p):
+        assert np.allclose(whole[c]["Gamma.con"], res[c]["Gamma.con"], rtol=1e-9, atol=1e-12)
+    # ---- the driver itself with one rank (no process group) on a device tensor
+    xd = torch.from_numpy(np.ascontiguousarray(x.T)).to(dev)
+    one = mdist.initseq_time_sharded(api.lagsums, api.initseq_from_lagsums, xd, n, halo)
+    for c in range(p):
+        assert np.allclose(one[c]["Gamma.con"], whole[c]["Gamma.con"], rtol=1e-9, atol=1e-12)
+    # ---- olbm by time on device tensors
+    blen = 500
+    tot = np.zeros((p, p))
+    for r in range(ws):
+        lo, hi, own = mdist.olbm_time_shard(n, blen, r, ws)
+        blk = torch.from_numpy(np.ascontiguousarray(x[lo:hi].T)).to(dev)
+        v, _ = api.olbm_device(blk, blen, mean=mean)
+        tot += v * (float(hi - lo - blen + 1) * (hi - lo) * blen)
+    got = tot / (float(n - blen + 1) * n * blen)
+    ref, _ = oracle_mod.olbm(x, blen)
+    assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))
+    v1, m1 = mdist.olbm_sharded(lambda xb, l, m: api.olbm_device(xb, l, mean=m)[0], xd, n, blen)
+    assert np.max(np.abs(v1 - ref)) <= 1e-10 * np.max(np.abs(ref)) and np.allclose(m1, mean, rtol=1e-13)

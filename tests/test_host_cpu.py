@@ -187,6 +187,29 @@ lo, hi, own = mdist.olbm_time_shard(n, blen, dist.get_rank(), 2)
 var, mean = mdist.olbm_sharded(lambda xb, l, m: oracle.olbm(xb, l, mean=m)[0], xs[lo:hi], n, blen)
 vref, mref = oracle.olbm(xs, blen)
 assert np.allclose(mean, mref, rtol=1e-14) and np.max(np.abs(var - vref)) <= 1e-12 * np.max(np.abs(vref))
+
+# initseq: TIME sharded with a halo; per round one all-reduce of raw lag sums (numpy lag sums stand in for the device
+# kernel; the stop rule and the sequences come from the library's host-only mcmchip_initseq_from_lagsums)
+from mcmc_amd import api
+def np_lagsums(x, nlags):
+    x = np.asarray(x)
+    return np.array([[np.dot(x[: x.shape[0] - l, c], x[l:, c]) if l < x.shape[0] else 0.0 for l in range(nlags)]
+                     for c in range(x.shape[1])])
+raw = np.column_stack(cols) + 1.5                 # not centred: the driver centres with the global mean
+halo = 400
+lo, hi, own = mdist.initseq_time_shard(raw.shape[0], halo, dist.get_rank(), 2)
+res = mdist.initseq_time_sharded(np_lagsums, api.initseq_from_lagsums, raw[lo:hi], raw.shape[0], halo, first_lags=16)
+for c in range(3):
+    ref = oracle.initseq(raw[:, c] - raw[:, c].mean())
+    assert len(res[c]["Gamma.pos"]) == len(ref["Gamma.pos"]), c
+    for key in ("gamma0", "Gamma.pos", "Gamma.dec", "Gamma.con", "var.pos", "var.dec", "var.con"):
+        assert np.max(np.abs(np.asarray(res[c][key]) - np.asarray(ref[key]))) <= 1e-10 * np.max(np.abs(ref[key])), (c, key)
+lo8, hi8, _ = mdist.initseq_time_shard(raw.shape[0], 8, dist.get_rank(), 2)
+try:
+    mdist.initseq_time_sharded(np_lagsums, api.initseq_from_lagsums, raw[lo8:hi8], raw.shape[0], 8, first_lags=8)
+    raise SystemExit("a halo of 8 rows cannot hold the stopping lag of the rho = 0.9 column")
+except RuntimeError as e:
+    assert "beyond the halo" in str(e)
 dist.destroy_process_group()
 print("ok")
 '''
