@@ -35,6 +35,7 @@
 // Roofline: fp64 MFMA.  Algorithmic flops per launch = 2 * n * d * C.
 #include "kernels.h"
 #include "philox.h"
+#include <type_traits>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -110,10 +111,31 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifndef IL_V
-#define IL_V 4
-#define IL_D 1
-#endif
+// Schedule of one tile (measured with tools/fp64_sustain_probe, profiles/r2_fp64_sustain_probe.txt): the fp64 MFMA
+// and the fp64 VALU share the SIMD's pipe, a lone wave keeps it full (64 cycles per MFMA back to back), vector
+// instructions ADD their 4.2 cycles each, and every switch between the two kinds costs about 6 cycles more.  The
+// first version of this kernel spread the softplus of the previous tile evenly between the MFMAs (one MFMA, 2-3 VALU):
+// 32 switches a tile.  Here a tile is MFMA groups of GK k-steps (GK * NC instructions) separated by VALU clusters:
+//     cluster q (after group q-1): evaluate the values whose table records were requested one cluster ago,
+//                                  form the table addresses of the next values (softplus.h: 8 + 3 instructions a value)
+//     then issue the LDS reads those addresses need, and the X fragments of the group after next: both have a whole
+//     MFMA group (>= 256 cycles) to land, so no s_waitcnt of the loop ever waits.
+// The values of the last cluster have nothing behind them to hide their table reads: they stay pending (their eta in
+// the accumulator registers, which the tile after next only overwrites with its first MFMA; their records in `pend`)
+// and are evaluated in cluster 0 of the next tile.
+template <int KS, int NC> struct TilePlan {
+    static constexpr int GK = KS >= 16 ? 4 : (KS >= 4 ? KS / 4 : 1);  // k-steps per MFMA group (>= 4 groups: <= 2 values a cluster)
+    static constexpr int NG = (KS + GK - 1) / GK;                     // groups = clusters per tile
+    static constexpr int NV = 4 * NC;                                 // softplus values per lane and tile
+    static constexpr int ad(int v) { return v * NG / NV; }            // cluster that forms the address of value v
+    static constexpr int npend()
+    {
+        int n = 0;
+        for (int v = 0; v < NV; v++) n += ad(v) == NG - 1;
+        return n;
+    }
+};
+
 template <int KS, int NC, int NW, int TC>
 __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__restrict__ xt,
                                                                const double *__restrict__ prop, long ldc,
@@ -121,12 +143,14 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
                                                                long tiles_per_split, long ntiles,
                                                                const SoftplusTables *__restrict__ tab)
 {
+    using P = TilePlan<KS, NC>;
+    constexpr int GK = P::GK, NG = P::NG, NV = P::NV, NP = P::npend();
     constexpr int CHUNK = TC * KS * 64;               // doubles per LDS buffer (16 KB)
     __shared__ __attribute__((aligned(16))) double smem[2 * CHUNK + SP_TAB_DOUBLES];
     double *sX = smem;
     double *sTab = smem + 2 * CHUNK;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < SP_TAB_DOUBLES; i += NW * 64) sTab[i] = tab->e[i];
 
     // loop-invariant B fragments: Theta[k = 4ks + (lane>>4)][chain = chain0 + 16c + (lane&15)]
@@ -147,13 +171,13 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     // LDS-DMA staging: a chunk is CHUNK/128 pieces of 1 KiB (64 lanes x 16 B), dealt round-robin to the waves
     constexpr int NPIECE = CHUNK / 128;
     auto stage = [&](long chunk, int buf) {
-        const double *g = gsrc + (size_t)chunk * CHUNK + lane * 2;
+        const double *gc = gsrc + (size_t)chunk * CHUNK;           // uniform
         double *l = sX + buf * CHUNK;
 #pragma unroll
         for (int i = 0; i < (NPIECE + NW - 1) / NW; i++) {
             const int piece = wave + i * NW;
             if (piece < NPIECE)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + piece * 128),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gc + piece * 128 + lane * 2),
                                                  (__attribute__((address_space(3))) void *)(l + piece * 128), 16, 0, 0);
         }
     };
@@ -166,101 +190,126 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     if (nchunks > 0) stage(0, 0);
     __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the table
 
-    // One tile = KS*NC MFMAs into a fresh accumulator set.  The softplus epilogue of a tile (softplus.h: per
-    // value 10 VALU instructions + the running sum and 4 ds_read_b128) is software-pipelined one tile behind: it is
-    // issued in the same basic block as the NEXT tile's MFMAs and spread between them with sched_group_barrier,
-    // so the latency of its table reads is covered by MFMAs in flight (measured: 156.8 -> 152.3 ms per launch, and 147.3 -> 144.5 with the reads two values ahead;
-    // its VALU instructions themselves cannot overlap the fp64 MFMA, see softplus.h).
-    auto mfma_tile = [&](const double *xs, int tt, double4_t *acc) {
-#pragma unroll
-        for (int c = 0; c < NC; c++) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const double a = xs[(tt * KS + ks) * 64];
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][c], acc[c], 0, 0, 0);
-        }
-    };
     // min(eta,0) - L(|eta|) = eta/2 - M(eta): sum(eta) is linear in Theta (colsum . theta, added by the update
     // kernel), so only M(eta) = |eta|/2 + L(|eta|) is accumulated here
-    auto epilogue = [&](const double4_t *acc) {
-        // the table reads of value v + SP_AHEAD are issued before value v is evaluated: with the one-MFMA distance the
-        // scheduler otherwise leaves between a read and its use, the LDS latency showed as s_waitcnt stalls
-        constexpr int NV = 4 * NC, SP_AHEAD = 2;
+    double4_t acc2[2][NC];        // ping-pong accumulators: tile tt uses acc2[tt & 1]
+    SoftplusRec pend[NP];         // table records of the pending values (an all-zero record evaluates to 0)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc2[i][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+
+    // xs: this lane's column of the tile in LDS.  accN: accumulators of this tile (on entry they still hold the tile
+    // before last, whose pending values cluster 0 evaluates).  accO: the finished previous tile.
+    auto tile_block = [&](const double *xs, double4_t *accN, const double4_t *accO, auto have_old) {
+#ifdef EXP_NO_EPILOGUE
+        constexpr bool OLD = false;
+#else
+        constexpr bool OLD = decltype(have_old)::value;
+#endif
+        double a[KS];
         uint32_t addr[NV];
         SoftplusRec rec[NV];
+        auto frags = [&](int g) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) addr[v] = softplus_lds_addr(acc[v / 4][v % 4], sp_shift);
+            for (int ks = g * GK; ks < (g + 1) * GK && ks < KS; ks++) a[ks] = xs[ks * 64];
+        };
+        // the compiler's s_waitcnt before an MFMA group waits for EVERY outstanding LDS read, so nothing may be issued
+        // between a cluster and the group behind it: the table reads go behind the first k-step of the group
+        auto mfma_ks = [&](int ks) {
 #pragma unroll
-        for (int v = 0; v < SP_AHEAD && v < NV; v++) softplus_lds_load(addr[v], rec[v]);
+            for (int c = 0; c < NC; c++)
+                #ifdef EXP_NO_EPILOGUE
+                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], accN[c], 0, 0, 0);
+#else
+                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
+#endif
+        };
+        frags(0);
+        if (NG > 1) frags(1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < NV; v++) {
-            if (v + SP_AHEAD < NV) softplus_lds_load(addr[v + SP_AHEAD], rec[v + SP_AHEAD]);
-            sum[v / 4] += softplus_lds_eval(acc[v / 4][v % 4], rec[v]);
+        for (int g = 0; g < NG; g++) {
+            // cluster g: evaluate the values addressed one cluster ago (cluster 0: the pending ones of the tile before
+            // last, still in accN), address the next ones
+            if (OLD) {
+                int ip = 0;
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    if (g == 0 && P::ad(v) == NG - 1) sum[v / 4] += softplus_lds_eval(accN[v / 4][v % 4], pend[ip++]);
+                    if (g > 0 && P::ad(v) == g - 1) sum[v / 4] += softplus_lds_eval(accO[v / 4][v % 4], rec[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+                    if (P::ad(v) == g) addr[v] = softplus_lds_addr(accO[v / 4][v % 4], sp_shift);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_ks(g * GK);
+            __builtin_amdgcn_sched_barrier(0);
+            if (OLD) {
+                int ip = 0;
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+                    if (P::ad(v) == g) {
+                        if (g == NG - 1) softplus_lds_load(addr[v], pend[ip++]);
+                        else softplus_lds_load(addr[v], rec[v]);
+                    }
+            }
+            if (g + 2 < NG) frags(g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = g * GK + 1; ks < (g + 1) * GK && ks < KS; ks++) mfma_ks(ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto interleave = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // the first X fragments
+    // after the last tile (accumulators accL; accP still holds the tile before it with its pending values)
+    auto drain = [&](const double4_t *accL, const double4_t *accP) {
+        int ip = 0;
 #pragma unroll
-        for (int i = 0; i < KS * NC / 2; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, IL_V, 0);  // VALU of the trailing epilogue
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // LDS reads: table pairs, X fragments
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, IL_V, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, IL_D, 0);
-        }
+        for (int v = 0; v < NV; v++)
+            if (P::ad(v) == NG - 1) sum[v / 4] += softplus_lds_eval(accP[v / 4][v % 4], pend[ip++]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) sum[v / 4] += softplus_half_abs_lds(accL[v / 4][v % 4], sp_shift);
+#ifdef EXP_NO_EPILOGUE
+#pragma unroll
+        for (int v = 0; v < NV; v++) sum[v / 4] += accP[v / 4][v % 4];
+#endif
     };
+    const std::true_type with_old;
+    const std::false_type first_tile;
 
-    double4_t acc2[2][NC];        // ping-pong accumulators: tile tt uses acc2[tt & 1]
     static_assert(TC == 1 || TC % 2 == 0, "the last tile of a chunk must leave its accumulators in acc2[1]");
     if (TC == 1) {
         // 64 < d <= 128: one 16-observation tile (KS up to 32 k-steps) fills a 16 KB buffer, so the chunk loop is
         // unrolled by two to keep the accumulator ping-pong static: even chunks use buffer 0 / acc2[0], odd ones 1
-        int last = 1;
         for (long ch = 0; ch < nchunks; ch += 2) {
             if (ch + 1 < nchunks) stage(ch + 1, 1);
-            mfma_tile(sX + lane, 0, acc2[0]);
-            if (ch > 0) {
-                epilogue(acc2[1]);
-                interleave();
-            }
+            if (ch == 0) tile_block(sX + lane, acc2[0], acc2[1], first_tile);
+            else tile_block(sX + lane, acc2[0], acc2[1], with_old);
             __syncthreads();
-            last = 0;
             if (ch + 1 >= nchunks) break;
             if (ch + 2 < nchunks) stage(ch + 2, 0);
-            mfma_tile(sX + CHUNK + lane, 0, acc2[1]);
-            epilogue(acc2[0]);
-            interleave();
+            tile_block(sX + CHUNK + lane, acc2[1], acc2[0], with_old);
             __syncthreads();
-            last = 1;
         }
         if (nchunks > 0) {
-            if (last == 0) epilogue(acc2[0]);
-            else epilogue(acc2[1]);
+            if (nchunks & 1) drain(acc2[0], acc2[1]);
+            else drain(acc2[1], acc2[0]);
         }
     } else {
         for (long ch = 0; ch < nchunks; ch++) {
             const int buf = (int)(ch & 1);
             if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
             const double *xs = sX + buf * CHUNK + lane;
-            if (ch == 0) {
-                mfma_tile(xs, 0, acc2[0]);
-            } else {
-                mfma_tile(xs, 0, acc2[0]);
-                epilogue(acc2[1]);                 // the last tile of the previous chunk
-                interleave();
-            }
+            if (ch == 0) tile_block(xs, acc2[0], acc2[1], first_tile);
+            else tile_block(xs, acc2[0], acc2[1], with_old);
 #pragma unroll
-            for (int tt = 1; tt < TC; tt++) {
-                mfma_tile(xs, tt, acc2[tt & 1]);
-                epilogue(acc2[(tt + 1) & 1]);
-                interleave();
-            }
+            for (int tt = 1; tt < TC; tt++) tile_block(xs + tt * KS * 64, acc2[tt & 1], acc2[(tt + 1) & 1], with_old);
             __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
         }
-        if (nchunks > 0) epilogue(acc2[1]);
+        if (nchunks > 0) drain(acc2[1], acc2[0]);
     }
 
     // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
