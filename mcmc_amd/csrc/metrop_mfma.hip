@@ -27,9 +27,9 @@
 // at the chain count: a sharded run that must reproduce an unsharded one pins `path`.
 //
 // HBM layout: X is stored once per target as sign-folded fragment-major tiles
-//   xt[tile][kstep][lane] = s_row * X[16*tile + (lane&15)][4*kstep + (lane>>4)],  s = +1 (y==1) / -1 (y==0)
-// so that min(s*eta,0) - L(|eta|) needs no label in the loop and a wave's A fragment is one
-// coalesced 512-B row.  State, proposal and batch accumulators are dimension-major
+//   xt[tile][kstep/2][lane][kstep%2] = s_row * X[16*tile + (lane&15)][4*kstep + (lane>>4)],  s = +1 (y==1) / -1 (y==0)
+// so that min(s*eta,0) - L(|eta|) needs no label in the loop and the A fragments of two k-steps are one coalesced
+// 16-byte-per-lane load (1 KiB a wave).  State, proposal and batch accumulators are dimension-major
 // ([d][C], "SoA") so that both the per-chain update kernel and the B-fragment loads coalesce.
 //
 // Roofline: fp64 MFMA.  Algorithmic flops per launch = 2 * n * d * C.
@@ -51,10 +51,11 @@ __global__ void tile_x_kernel(const double *__restrict__ x, const double *__rest
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = ntiles * ksteps * 64;
     if (idx >= total) return;
-    int lane = (int)(idx & 63);
-    long tk = idx >> 6;
-    int ks = (int)(tk % ksteps);
-    long t = tk / ksteps;
+    const int j = (int)(idx & 1);
+    int lane = (int)((idx >> 1) & 63);
+    long tk = idx >> 7;                    // (tile, k-step pair)
+    int ks = 2 * (int)(tk % (ksteps / 2)) + j;
+    long t = tk / (ksteps / 2);
     long row = t * 16 + (lane & 15);
     int col = 4 * ks + (lane >> 4);
     double v = 0.0;
@@ -73,11 +74,11 @@ __global__ __launch_bounds__(256) void tile_colsum_kernel(const double *__restri
     const int col = blockIdx.x;                 // 0 .. dpad-1
     const int ks = col >> 2, kk = col & 3;
     double s = 0.0;
-    // element (tile t, row r) of column col sits at xt[((t*ksteps + ks)*64) + kk*16 + r]
+    // element (tile t, row r) of column col sits at xt[((t*ksteps/2 + ks/2)*64 + kk*16 + r)*2 + ks%2]
     for (long i = threadIdx.x; i < ntiles * 16; i += 256) {
         const long t = i >> 4;
         const int r = (int)(i & 15);
-        s += xt[((size_t)t * ksteps + ks) * 64 + kk * 16 + r];
+        s += xt[(((size_t)t * (ksteps / 2) + (ks >> 1)) * 64 + kk * 16 + r) * 2 + (ks & 1)];
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -145,10 +146,10 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 {
     using P = TilePlan<KS, NC>;
     constexpr int GK = P::GK, NG = P::NG, NV = P::NV, NP = P::npend();
-    constexpr int CHUNK = TC * KS * 64;               // doubles per LDS buffer (16 KB)
-    __shared__ __attribute__((aligned(16))) double smem[2 * CHUNK + SP_TAB_DOUBLES];
-    double *sX = smem;
-    double *sTab = smem + 2 * CHUNK;
+    // LDS holds the softplus table only.  The X fragments go from global memory straight into registers: the waves
+    // of a workgroup (and all workgroups of an XCD) read the same tiles at about the same time, so one of them pays
+    // the HBM / L2 miss and the rest hit the CU's vector cache or the XCD's L2; no staging, no barrier in the loop.
+    __shared__ __attribute__((aligned(32))) double sTab[SP_TAB_DOUBLES];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < SP_TAB_DOUBLES; i += NW * 64) sTab[i] = tab->e[i];
@@ -165,30 +166,13 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     const long t0 = (long)blockIdx.y * tiles_per_split;
     long t1 = t0 + tiles_per_split;
     if (t1 > ntiles) t1 = ntiles;
-    const long nchunks = (t1 - t0) / TC;
-    const double *gsrc = xt + (size_t)t0 * KS * 64;
-
-    // LDS-DMA staging: a chunk is CHUNK/128 pieces of 1 KiB (64 lanes x 16 B), dealt round-robin to the waves
-    constexpr int NPIECE = CHUNK / 128;
-    auto stage = [&](long chunk, int buf) {
-        const double *gc = gsrc + (size_t)chunk * CHUNK;           // uniform
-        double *l = sX + buf * CHUNK;
-#pragma unroll
-        for (int i = 0; i < (NPIECE + NW - 1) / NW; i++) {
-            const int piece = wave + i * NW;
-            if (piece < NPIECE)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gc + piece * 128 + lane * 2),
-                                                 (__attribute__((address_space(3))) void *)(l + piece * 128), 16, 0, 0);
-        }
-    };
 
     const double sp_shift = softplus_lds_shift(sTab);
     double sum[NC];               // sum of M(eta) = |eta|/2 + L(|eta|)
 #pragma unroll
     for (int c = 0; c < NC; c++) sum[c] = 0.0;
 
-    if (nchunks > 0) stage(0, 0);
-    __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the table
+    __syncthreads();   // publishes the table
 
     // min(eta,0) - L(|eta|) = eta/2 - M(eta): sum(eta) is linear in Theta (colsum . theta, added by the update
     // kernel), so only M(eta) = |eta|/2 + L(|eta|) is accumulated here
@@ -201,21 +185,35 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 #pragma unroll
     for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
-    // xs: this lane's column of the tile in LDS.  accN: accumulators of this tile (on entry they still hold the tile
-    // before last, whose pending values cluster 0 evaluates).  accO: the finished previous tile.
-    auto tile_block = [&](const double *xs, double4_t *accN, const double4_t *accO, auto have_old) {
+    // a[]: this lane's X fragments of the tile about to be multiplied; tile_block refills each group's registers with
+    // the NEXT tile's fragments (nx: this lane's column of it in global memory) as soon as the group has been issued,
+    // so a load has NG-1 groups (about 1.6 us at d = 64) to arrive.  accN: accumulators of this tile (on entry they
+    // still hold the tile before last, whose pending values cluster 0 evaluates).  accO: the finished previous tile.
+    double a[KS];
+    // k-steps [k0, k1) of a tile column: 16-byte loads of the pairs the range covers whole, 8-byte loads at odd ends
+    auto refill = [&](const double *__restrict__ colp, int k0, int k1) {
+#pragma unroll
+        for (int kp = k0 >> 1; 2 * kp < k1; kp++) {
+            const bool lo = 2 * kp >= k0, hi = 2 * kp + 1 < k1;
+            if (lo && hi) {
+                const double2 p = *(const double2 *)(colp + kp * 128);
+                a[2 * kp] = p.x;
+                a[2 * kp + 1] = p.y;
+            } else if (lo) {
+                a[2 * kp] = colp[kp * 128];
+            } else if (hi) {
+                a[2 * kp + 1] = colp[kp * 128 + 1];
+            }
+        }
+    };
+    auto tile_block = [&](const double *__restrict__ nx, double4_t *accN, const double4_t *accO, auto have_old) {
 #ifdef EXP_NO_EPILOGUE
         constexpr bool OLD = false;
 #else
         constexpr bool OLD = decltype(have_old)::value;
 #endif
-        double a[KS];
         uint32_t addr[NV];
         SoftplusRec rec[NV];
-        auto frags = [&](int g) {
-#pragma unroll
-            for (int ks = g * GK; ks < (g + 1) * GK && ks < KS; ks++) a[ks] = xs[ks * 64];
-        };
         // the compiler's s_waitcnt before an MFMA group waits for EVERY outstanding LDS read, so nothing may be issued
         // between a cluster and the group behind it: the table reads go behind the first k-step of the group
         auto mfma_ks = [&](int ks) {
@@ -227,9 +225,6 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
                 accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
 #endif
         };
-        frags(0);
-        if (NG > 1) frags(1);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             // cluster g: evaluate the values addressed one cluster ago (cluster 0: the pending ones of the tile before
@@ -257,10 +252,11 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
                         else softplus_lds_load(addr[v], rec[v]);
                     }
             }
-            if (g + 2 < NG) frags(g + 2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = g * GK + 1; ks < (g + 1) * GK && ks < KS; ks++) mfma_ks(ks);
+            __builtin_amdgcn_sched_barrier(0);
+            refill(nx, g * GK, (g + 1) * GK < KS ? (g + 1) * GK : KS);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -280,36 +276,24 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     const std::true_type with_old;
     const std::false_type first_tile;
 
-    static_assert(TC == 1 || TC % 2 == 0, "the last tile of a chunk must leave its accumulators in acc2[1]");
-    if (TC == 1) {
-        // 64 < d <= 128: one 16-observation tile (KS up to 32 k-steps) fills a 16 KB buffer, so the chunk loop is
-        // unrolled by two to keep the accumulator ping-pong static: even chunks use buffer 0 / acc2[0], odd ones 1
-        for (long ch = 0; ch < nchunks; ch += 2) {
-            if (ch + 1 < nchunks) stage(ch + 1, 1);
-            if (ch == 0) tile_block(sX + lane, acc2[0], acc2[1], first_tile);
-            else tile_block(sX + lane, acc2[0], acc2[1], with_old);
-            __syncthreads();
-            if (ch + 1 >= nchunks) break;
-            if (ch + 2 < nchunks) stage(ch + 2, 0);
-            tile_block(sX + CHUNK + lane, acc2[1], acc2[0], with_old);
-            __syncthreads();
+    // tiles t0 .. t1-1: the first has no previous tile, then pairs (odd tile -> acc2[1], even -> acc2[0]).  The tile
+    // after the last is never needed: its loads are pointed at the last tile again (inside the allocation).
+    if (t1 > t0) {
+        const double *xl = xt + (size_t)lane * 2;
+        auto col = [&](long t) { return xl + (size_t)(t < t1 ? t : t1 - 1) * (KS * 64); };
+        refill(col(t0), 0, KS);
+        tile_block(col(t0 + 1), acc2[0], acc2[1], first_tile);
+        long t = t0 + 1;
+        for (; t + 1 < t1; t += 2) {
+            tile_block(col(t + 1), acc2[1], acc2[0], with_old);
+            tile_block(col(t + 2), acc2[0], acc2[1], with_old);
         }
-        if (nchunks > 0) {
-            if (nchunks & 1) drain(acc2[0], acc2[1]);
-            else drain(acc2[1], acc2[0]);
+        if (t < t1) {
+            tile_block(col(t + 1), acc2[1], acc2[0], with_old);
+            drain(acc2[1], acc2[0]);
+        } else {
+            drain(acc2[0], acc2[1]);
         }
-    } else {
-        for (long ch = 0; ch < nchunks; ch++) {
-            const int buf = (int)(ch & 1);
-            if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
-            const double *xs = sX + buf * CHUNK + lane;
-            if (ch == 0) tile_block(xs, acc2[0], acc2[1], first_tile);
-            else tile_block(xs, acc2[0], acc2[1], with_old);
-#pragma unroll
-            for (int tt = 1; tt < TC; tt++) tile_block(xs + tt * KS * 64, acc2[tt & 1], acc2[(tt + 1) & 1], with_old);
-            __syncthreads();   // next buffer landed (vmcnt(0) + barrier); this buffer free for restaging
-        }
-        if (nchunks > 0) drain(acc2[1], acc2[0]);
     }
 
     // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups

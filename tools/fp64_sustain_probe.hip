@@ -28,6 +28,9 @@ __global__ __launch_bounds__(1024) void probe(double *out, long long *clk, int i
         if (KIND == 0) {
 #pragma unroll
             for (int m = 0; m < 16; m++) acc[m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[m & 3], 0, 0, 0);
+        } else if (KIND >= 41 && KIND <= 44) {      // 16 MFMA round-robin over KIND - 40 accumulators (dependent every n-th)
+#pragma unroll
+            for (int m = 0; m < 16; m++) acc[m % (KIND - 40)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[m % (KIND - 40)], 0, 0, 0);
         } else if (KIND == 1) {
 #pragma unroll
             for (int q = 0; q < 128; q++) v[q & 7] = __builtin_fma(v[q & 7], 0.999999, 1e-9);
@@ -110,6 +113,9 @@ int main()
             run<0>("mfma", used[u], t, 40000 * 256 / t, wall_khz);
             run<1>("fma", used[u], t, 20000 * 256 / t, wall_khz);
             if (u == 0) {
+                run<41>("mfma 1 acc", used[u], t, 40000 * 256 / t, wall_khz);
+                run<42>("mfma 2 acc", used[u], t, 40000 * 256 / t, wall_khz);
+                run<43>("mfma 3 acc", used[u], t, 40000 * 256 / t, wall_khz);
                 run<2>("mfma+4fma/8ch", used[u], t, 40000 * 256 / t, wall_khz);
                 run<3>("mfma+4fma/2ch", used[u], t, 40000 * 256 / t, wall_khz);
                 run<4>("mfma+4fma/1ch", used[u], t, 40000 * 256 / t, wall_khz);
