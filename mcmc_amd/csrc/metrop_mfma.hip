@@ -12,7 +12,7 @@
 //       its share of the observation tiles of X through a double-buffered 16 KB LDS ring filled by LDS-DMA
 //       (global_load_lds, 16 B/lane), so X is read once per workgroup from HBM/L2 and each 16-observation tile
 //       feeds 16 * NC v_mfma_f64_16x16x4_f64 per wave.  The accumulator tile (4 observations x 1 chain per lane)
-//       goes straight through the softplus epilogue (softplus.h: 11 VALU instructions per value, a degree-6
+//       goes straight through the softplus epilogue (softplus.h: 10 VALU instructions per value, a degree-5
 //       expansion of |eta|/2 + log1p(exp(-|eta|)) around the nearest of 2035 grid points held in LDS) and into
 //       a per-lane running sum: eta never leaves registers.  The epilogue of tile t is issued between the MFMAs
 //       of tile t+1.
@@ -118,7 +118,7 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 // first version of this kernel spread the softplus of the previous tile evenly between the MFMAs (one MFMA, 2-3 VALU):
 // 32 switches a tile.  Here a tile is MFMA groups of GK k-steps (GK * NC instructions) separated by VALU clusters:
 //     cluster q (after group q-1): evaluate the values whose table records were requested one cluster ago,
-//                                  form the table addresses of the next values (softplus.h: 8 + 3 instructions a value)
+//                                  form the table addresses of the next values (softplus.h: 7 + 3 instructions a value)
 //     then issue the LDS reads those addresses need, and the X fragments of the group after next: both have a whole
 //     MFMA group (>= 256 cycles) to land, so no s_waitcnt of the loop ever waits.
 // The values of the last cluster have nothing behind them to hide their table reads: they stay pending (their eta in
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 #pragma unroll
         for (int c = 0; c < NC; c++) acc2[i][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
     // a[]: this lane's X fragments of the tile about to be multiplied; tile_block refills each group's registers with
     // the NEXT tile's fragments (nx: this lane's column of it in global memory) as soon as the group has been issued,

@@ -11,19 +11,24 @@
 // fp64 VALU op of this epilogue is paid in MFMA time, so the op count is what matters.  Library
 // exp()/log1p() cost ~150 fp64 ops; the previous version of this file (table of {L_j, sigma_j} + an expm1 and a
 // log1p series, clamp and a separate sum of |eta|) cost 17.  Here M is expanded directly around the nearest
-// point of a grid a_j = j/56.5, j = 0..2034 (|r| <= 1/113):
-//     M(a_j + r) = c0 + r (c1 + r (c2 + r (c3 + r (c4 + r (c5 + r c6))))),   c_k = M^(k)(a_j) / k!
-// (remainder <= |L^(7)|/7! * r^7 < 1e-18).  Eight doubles per entry {a_j, c0..c6} = 130 KB of LDS, as two arrays
-// of 32-byte records ({a_j,c0,c1,c2} and {c3,c4,c5,c6}: four ds_read_b128 off one address register).
+// point of a grid a_j = j/56.5, j = 0..2034 (|r| <= H = 1/113) as a degree-5 polynomial
+//     M(a_j + r) ~ c0 + r (c1 + r (c2 + r (c3 + r (c4 + r c5)))),
+// the degree-6 Taylor polynomial (t_k = M^(k)(a_j) / k!) with its last term economised: on [-H, H]
+//     r^6 = H^6 T6(r/H)/32 + 1.5 H^2 r^4 - 0.5625 H^4 r^2 + H^6/32,   |T6| <= 1,
+// so c4 = t4 + 1.5 H^2 t6, c2 = t2 - 0.5625 H^4 t6, c0 = t0 + H^6 t6 / 32 and c1, c3, c5 = t1, t3, t5.  What is
+// dropped is <= |t6| H^6 / 32 + |t7| H^7 < 6e-18 (|M^(6)| <= 1/4), a twentieth of an ulp of M >= ln 2: one fma less
+// per value than the degree-6 Taylor form of the version before, at the same accuracy.  Eight doubles per entry
+// {a_j, c0..c5, 0} = 130 KB of LDS, as two arrays of 32-byte records ({a_j,c0,c1,c2} and {c3,c4,c5,0}: three
+// ds_read_b128 and a ds_read_b64 off one address register).
 // Measured on the box (exp builds of the MFMA kernel): v_mfma_f64_16x16x4 occupies the SIMD's VALU for its 64
 // cycles, so EVERY VALU instruction of the epilogue -- integer ones too -- adds its issue time to the kernel,
 // while the table reads themselves cost almost nothing.  The epilogue is therefore written for instruction
-// count: 1 v_min_f64 (clamp for the index), 1 fma (index), 1 shift (address), 1 subtract (r), 6 fma, and the
-// caller's running sum = **11 VALU instructions** per value (the {L_j, sigma_j} + expm1/log1p-series version
-// before it: 20).
+// count: 1 v_min_f64 (clamp for the index), 1 fma (index), 1 shift (address), 1 subtract (r), 5 fma, and the
+// caller's running sum = **10 VALU instructions** per value (degree-6 Taylor: 11; the {L_j, sigma_j} +
+// expm1/log1p-series version before that: 20).
 // Beyond the table (|eta| > 36) the index stays in the last cell (the clamp) while r keeps growing, and the last
 // record holds the line c0 + r/2 (L(36) = 2.3e-16 is constant to 1 ulp of M there; its higher coefficients are
-// 1e-300 rather than 0 so that |eta| = Inf gives +Inf, not NaN; |eta| up to 1e40 is exact to rounding).
+// 1e-300 rather than 0 so that |eta| = Inf gives +Inf, not NaN; |eta| up to 1e50 is exact to rounding).
 // NaN propagates.
 //
 // Accuracy (tools/check_softplus.py against long double): <= 2 ulp of M (mean 0.3) for |eta| up to 1e30.
@@ -42,17 +47,17 @@
 #define SP_AMAX 36
 #define SP_SCALE 56.5                        // grid points per unit (exact in binary)
 #define SP_N 2035                            // SP_AMAX * SP_SCALE + 1
-#define SP_DEG 6
+#define SP_DEG 6                             // degree of the Taylor polynomial the table is built from (evaluated: 5)
 #define SP_ACLAMP 36.0078125                 // < 36 + 0.5/SP_SCALE: the index never leaves the table
 
 struct SoftplusTables {
-    double e[4 * 2 * SP_N];   // SP_N records {a_j, c0, c1, c2}, then SP_N records {c3, c4, c5, c6}
+    double e[4 * 2 * SP_N];   // SP_N records {a_j, c0, c1, c2}, then SP_N records {c3, c4, c5, 0}
 };
 #define SP_TAB_DOUBLES (4 * 2 * SP_N)
 
 SP_HD double sp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// tab may live in LDS or host memory.  Layout: SP_N records {a_j, c0, c1, c2}, then SP_N records {c3, c4, c5, c6}.
+// tab may live in LDS or host memory.  Layout: SP_N records {a_j, c0, c1, c2}, then SP_N records {c3, c4, c5, 0}.
 SP_HD double softplus_half_abs(double eta, const double *tab)
 {
     const double SHIFT = 6755399441055744.0;   // 1.5 * 2^52: low mantissa bits of (x + SHIFT) = rint(x)
@@ -71,8 +76,7 @@ SP_HD double softplus_half_abs(double eta, const double *tab)
     const uint32_t j = (uint32_t)bits;           // 0 .. SP_N-1 by construction of the clamp
     const double *t0 = tab + 4 * j, *t1 = t0 + 4 * SP_N;
     const double r = __builtin_fabs(eta) - t0[0];
-    double q = sp_fma(r, t1[3], t1[2]);
-    q = sp_fma(r, q, t1[1]);
+    double q = sp_fma(r, t1[2], t1[1]);
     q = sp_fma(r, q, t1[0]);
     q = sp_fma(r, q, t0[3]);
     q = sp_fma(r, q, t0[2]);
@@ -98,8 +102,8 @@ __device__ __forceinline__ double softplus_lds_shift(const double *tab_in_lds)
     return 0.0;        // device-only (the host pass of hipcc only needs the declaration)
 #endif
 }
-// Split in three so that a caller can software-pipeline: address (3 VALU), the four 16-byte table reads, evaluation
-// (8 VALU).  softplus_half_abs_lds() is the three in a row.
+// Split in three so that a caller can software-pipeline: address (3 VALU), the four table reads, evaluation
+// (7 VALU with the caller's running sum).  softplus_half_abs_lds() is the three in a row.
 __device__ __forceinline__ uint32_t softplus_lds_addr(double eta, double shiftb)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -113,20 +117,19 @@ __device__ __forceinline__ uint32_t softplus_lds_addr(double eta, double shiftb)
     return 0u;         // device-only (the host pass of hipcc only needs the declaration)
 #endif
 }
-struct SoftplusRec { double a, c0, c1, c2, c3, c4, c5, c6; };
+struct SoftplusRec { double a, c0, c1, c2, c3, c4, c5; };
 __device__ __forceinline__ void softplus_lds_load(uint32_t addr, SoftplusRec &t)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     sp_lds_cd *t0 = (sp_lds_cd *)(uintptr_t)addr, *t1 = t0 + 4 * SP_N;
     t.a = t0[0]; t.c0 = t0[1]; t.c1 = t0[2]; t.c2 = t0[3];
-    t.c3 = t1[0]; t.c4 = t1[1]; t.c5 = t1[2]; t.c6 = t1[3];
+    t.c3 = t1[0]; t.c4 = t1[1]; t.c5 = t1[2];
 #endif
 }
 __device__ __forceinline__ double softplus_lds_eval(double eta, const SoftplusRec &t)
 {
     const double r = __builtin_fabs(eta) - t.a;
-    double q = sp_fma(r, t.c6, t.c5);
-    q = sp_fma(r, q, t.c4);
+    double q = sp_fma(r, t.c5, t.c4);
     q = sp_fma(r, q, t.c3);
     q = sp_fma(r, q, t.c2);
     q = sp_fma(r, q, t.c1);
@@ -177,20 +180,27 @@ static inline void softplus_tables_init(SoftplusTables *t)
         const double aj = (double)((long double)j / (long double)SP_SCALE);
         const long double ex = expl(-(long double)aj);
         const long double s = ex / (1.0L + ex);
-        double c[SP_DEG + 1];
-        c[0] = (double)((long double)aj / 2 + log1pl(ex));
+        long double tk[SP_DEG + 1];                 // Taylor coefficients of M at a_j
+        tk[0] = (long double)aj / 2 + log1pl(ex);
         for (int k = 1; k <= SP_DEG; k++) {
             long double v = 0.0L;
             for (int m = k; m >= 1; m--) v = v * s + poly[k][m];     // Horner in s, p_k has no constant term
             v *= s;
-            c[k] = (double)(v / kfact[k] + (k == 1 ? 0.5L : 0.0L));
+            tk[k] = v / kfact[k] + (k == 1 ? 0.5L : 0.0L);
         }
+        const long double H = 0.5L / (long double)SP_SCALE, H2 = H * H;
+        tk[4] += 1.5L * H2 * tk[6];                 // economise t6 r^6 (header)
+        tk[2] -= 0.5625L * H2 * H2 * tk[6];
+        tk[0] += H2 * H2 * H2 * tk[6] / 32.0L;
+        double c[SP_DEG];
+        for (int k = 0; k < SP_DEG; k++) c[k] = (double)tk[k];
         if (j == SP_N - 1) {                       // the line beyond the table
+            c[0] = (double)((long double)aj / 2 + log1pl(ex));
             c[1] = 0.5;
-            for (int k = 2; k <= SP_DEG; k++) c[k] = 1e-300;
+            for (int k = 2; k < SP_DEG; k++) c[k] = 1e-300;
         }
         double *r0 = t->e + 4 * j, *r1 = t->e + 4 * SP_N + 4 * j;
         r0[0] = aj;   r0[1] = c[0]; r0[2] = c[1]; r0[3] = c[2];
-        r1[0] = c[3]; r1[1] = c[4]; r1[2] = c[5]; r1[3] = c[6];
+        r1[0] = c[3]; r1[1] = c[4]; r1[2] = c[5]; r1[3] = 0.0;
     }
 }
