@@ -190,19 +190,22 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     // so a load has NG-1 groups (about 1.6 us at d = 64) to arrive.  accN: accumulators of this tile (on entry they
     // still hold the tile before last, whose pending values cluster 0 evaluates).  accO: the finished previous tile.
     double a[KS];
-    // k-steps [k0, k1) of a tile column: 16-byte loads of the pairs the range covers whole, 8-byte loads at odd ends
+    // k-steps [k0, k1) of a tile (colp: the tile's first double, uniform; each lane adds its 16-byte slot last, so the
+    // address is scalar base + lane offset): 16-byte loads of the pairs the range covers whole, 8-byte loads at odd ends
+    const int lane2 = lane * 2;
     auto refill = [&](const double *__restrict__ colp, int k0, int k1) {
 #pragma unroll
         for (int kp = k0 >> 1; 2 * kp < k1; kp++) {
             const bool lo = 2 * kp >= k0, hi = 2 * kp + 1 < k1;
+            const double *q = colp + kp * 128;
             if (lo && hi) {
-                const double2 p = *(const double2 *)(colp + kp * 128);
+                const double2 p = *(const double2 *)(q + lane2);
                 a[2 * kp] = p.x;
                 a[2 * kp + 1] = p.y;
             } else if (lo) {
-                a[2 * kp] = colp[kp * 128];
+                a[2 * kp] = q[lane2];
             } else if (hi) {
-                a[2 * kp + 1] = colp[kp * 128 + 1];
+                a[2 * kp + 1] = q[lane2 + 1];
             }
         }
     };
@@ -278,18 +281,19 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 
     // tiles t0 .. t1-1: the first has no previous tile, then pairs (odd tile -> acc2[1], even -> acc2[0]).  The tile
     // after the last is never needed: its loads are pointed at the last tile again (inside the allocation).
-    if (t1 > t0) {
-        const double *xl = xt + (size_t)lane * 2;
-        auto col = [&](long t) { return xl + (size_t)(t < t1 ? t : t1 - 1) * (KS * 64); };
-        refill(col(t0), 0, KS);
-        tile_block(col(t0 + 1), acc2[0], acc2[1], first_tile);
-        long t = t0 + 1;
-        for (; t + 1 < t1; t += 2) {
-            tile_block(col(t + 1), acc2[1], acc2[0], with_old);
-            tile_block(col(t + 2), acc2[0], acc2[1], with_old);
+    const int nt = (int)(t1 - t0);               // 32-bit tile counters: the scalar unit has no 64-bit ordered compare
+    if (nt > 0) {
+        const double *x0 = xt + (size_t)t0 * (KS * 64);
+        auto col = [&](int i) { return x0 + (size_t)(i < nt ? i : nt - 1) * (KS * 64); };
+        refill(col(0), 0, KS);
+        tile_block(col(1), acc2[0], acc2[1], first_tile);
+        int i = 1;
+        for (; i + 1 < nt; i += 2) {
+            tile_block(col(i + 1), acc2[1], acc2[0], with_old);
+            tile_block(col(i + 2), acc2[0], acc2[1], with_old);
         }
-        if (t < t1) {
-            tile_block(col(t + 1), acc2[1], acc2[0], with_old);
+        if (i < nt) {
+            tile_block(col(i + 1), acc2[1], acc2[0], with_old);
             drain(acc2[1], acc2[0]);
         } else {
             drain(acc2[0], acc2[1]);
