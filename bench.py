@@ -176,7 +176,7 @@ def main():
     # process, so the recorded rocprofv3 measurement of the same workload is reported (or null)
     traffic = None
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
         if rec["workload"] == {"n": a.n, "d": a.d, "chains_per_gpu": Cn}:
             traffic = rec["hbm_bytes_per_launch"]
     except Exception:
@@ -201,7 +201,7 @@ def main():
                        "note": "timed call = %d iterations + the call's initial-state density evaluation" % a.steps},
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_pmc_traffic.json)",
                          "launch_ms": kms, "launches_timed": klaunch,
                          "flops_per_launch": flops_per_launch},
         }

@@ -6,16 +6,18 @@
 // chain-iteration, followed by n softplus evaluations per chain.
 //
 // Per Metropolis iteration two kernels run on the library stream:
-//   logdens_mfma_kernel  grid (ceil(C / 256), nsplit): a workgroup of MFMA_NW = 8 wavefronts (two per SIMD: the
-//       second fills the dependency gaps of the fp64 MFMA) owns 256 chains; wave w owns MFMA_NC = 2 tiles of 16
-//       chains whose Theta fragments stay in VGPRs for the whole launch (loop invariant).  The workgroup streams
-//       its share of the observation tiles of X through a double-buffered 16 KB LDS ring filled by LDS-DMA
-//       (global_load_lds, 16 B/lane), so X is read once per workgroup from HBM/L2 and each 16-observation tile
-//       feeds 16 * NC v_mfma_f64_16x16x4_f64 per wave.  The accumulator tile (4 observations x 1 chain per lane)
-//       goes straight through the softplus epilogue (softplus.h: 10 VALU instructions per value, a degree-5
-//       expansion of |eta|/2 + log1p(exp(-|eta|)) around the nearest of 2035 grid points held in LDS) and into
-//       a per-lane running sum: eta never leaves registers.  The epilogue of tile t is issued between the MFMAs
-//       of tile t+1.
+//   logdens_mfma_kernel  grid (ceil(C / 256), nsplit): a workgroup of MFMA_NW = 8 wavefronts (two per SIMD) owns 256
+//       chains; wave w owns MFMA_NC = 2 tiles of 16 chains whose Theta fragments stay in VGPRs for the whole launch
+//       (loop invariant).  Every wave reads the X fragments of its share of the observation tiles straight from
+//       global memory into registers, one tile ahead (16-byte loads; all waves of a CU and all CUs of an XCD read the
+//       same tiles at about the same time, so X comes from HBM once per XCD and from the vector cache / L2
+//       otherwise): no LDS staging, no barrier in the loop.  Each 16-observation tile feeds 16 * NC
+//       v_mfma_f64_16x16x4_f64 per wave.  The accumulator tile (4 observations x 1 chain per lane) goes straight
+//       through the softplus epilogue (softplus.h: 10 VALU instructions per value, a degree-5 expansion of
+//       |eta|/2 + log1p(exp(-|eta|)) around the nearest of 2035 grid points held in LDS, 130 KB) and into a per-lane
+//       running sum: eta never leaves registers.  The epilogue of tile t runs as four clusters of vector
+//       instructions between the four MFMA groups of tile t+1 (TilePlan below: why clusters and not an even
+//       interleave).
 //   metrop_update_kernel one lane per chain: fixed-order sum of the nsplit partials, prior term, accept rule
 //       (metrop.c:225-235), state/batch-means bookkeeping, Philox normals and the next proposal.
 //
@@ -39,9 +41,9 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-#define MFMA_NW 8          // wavefronts per workgroup (2 per SIMD: a second wave fills MFMA dependency gaps)
+#define MFMA_NW 8          // wavefronts per workgroup (2 per SIMD: one covers the other's waits on loads and table reads)
 #define MFMA_NC 2          // 16-chain tiles per wavefront -> 256 chains per workgroup
-// observation tiles per LDS chunk: 16 KB per buffer whatever d is
+// granularity of the tile count (build_mfma_tiles pads n to it with zero rows) and of an observation split
 static inline int mfma_tc(int ks) { return ks <= 2 ? 16 : (ks <= 4 ? 8 : (ks <= 8 ? 4 : (ks <= 16 ? 2 : 1))); }
 
 // ---------------------------------------------------------------------------------------------
@@ -210,11 +212,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         }
     };
     auto tile_block = [&](const double *__restrict__ nx, double4_t *accN, const double4_t *accO, auto have_old) {
-#ifdef EXP_NO_EPILOGUE
-        constexpr bool OLD = false;
-#else
         constexpr bool OLD = decltype(have_old)::value;
-#endif
         uint32_t addr[NV];
         SoftplusRec rec[NV];
         // the compiler's s_waitcnt before an MFMA group waits for EVERY outstanding LDS read, so nothing may be issued
@@ -222,11 +220,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         auto mfma_ks = [&](int ks) {
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                #ifdef EXP_NO_EPILOGUE
-                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], accN[c], 0, 0, 0);
-#else
-                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
-#endif
+                                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
         };
 #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -271,10 +265,6 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
             if (P::ad(v) == NG - 1) sum[v / 4] += softplus_lds_eval(accP[v / 4][v % 4], pend[ip++]);
 #pragma unroll
         for (int v = 0; v < NV; v++) sum[v / 4] += softplus_half_abs_lds(accL[v / 4][v % 4], sp_shift);
-#ifdef EXP_NO_EPILOGUE
-#pragma unroll
-        for (int v = 0; v < NV; v++) sum[v / 4] += accP[v / 4][v % 4];
-#endif
     };
     const std::true_type with_old;
     const std::false_type first_tile;
@@ -481,6 +471,9 @@ static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
     // one workgroup per CU (LDS-bound occupancy).  A grid that is a whole number of chip-fulls needs no
     // observation split; otherwise split the observations until the tail round is small, keeping
     // >= 2 chunks per workgroup (with 8 a 4096 x 5 posterior over 4096 chains ran on 32 workgroups).
+    // (Tried: an 8-way split decoded so that each XCD streams its own eighth of X.  The HBM-side read count did not
+    // move -- an XCD then re-streams its eighth once per round of 32 workgroups, 8 rounds -- and the launch got 0.7 %
+    // slower; the L2s request X from the fabric 8 to 16 times per launch either way, under 1 % of the HBM rate.)
     long want = 1;
     if (pl.chain_blocks % num_cu != 0) {
         want = (4L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;

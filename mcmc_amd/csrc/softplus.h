@@ -7,7 +7,7 @@
 // L(a) = log1p(exp(-a)).  The s*eta/2 part is linear in theta (a column-sum dot product, added by the update
 // kernel), so the per-observation work is M alone.
 //
-// On gfx950 the fp64 MFMA and the fp64 VALU share one pipe (profiles/r1_mfma64_probe.txt): every
+// On gfx950 the fp64 MFMA and the fp64 VALU share one pipe (profiles/r2_fp64_sustain_probe.txt): every
 // fp64 VALU op of this epilogue is paid in MFMA time, so the op count is what matters.  Library
 // exp()/log1p() cost ~150 fp64 ops; the previous version of this file (table of {L_j, sigma_j} + an expm1 and a
 // log1p series, clamp and a separate sum of |eta|) cost 17.  Here M is expanded directly around the nearest
