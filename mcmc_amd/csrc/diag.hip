@@ -800,11 +800,17 @@ template <int F> struct OmShape {
     // LD = 2 mod 4: the two fragment rows a 32-lane ds_read_b64 group touches are 8 rows = 32 banks apart
     // (conflict-free); the transposed ds_write_b64 of the producer is 2-way, off the critical path
     static constexpr int LD = PP + DUPC + 2;
-    static constexpr int NLD = PP / (4 * OM_NW);        // columns each thread produces per slab
+    static constexpr int NLD = PP / (4 * OM_NW);        // 4-column load slots of a wave per slab
+    static constexpr int CW = PP / OM_NW;               // columns a wave produces (contiguous): 8, 16, 32
+    static constexpr int NPART = 64 / CW;               // a column's 16 windows are summed by NPART lanes ...
+    static constexpr int WPP = OM_SLAB / NPART;         // ... WPP consecutive windows each
+    // per-wave image of the differences x[t+len] - x[t], [column][window]; 18 doubles = 144 B per column: the 16-byte
+    // reads of 8 consecutive lanes (columns) fall in 8 disjoint bank groups
+    static constexpr int DLD = OM_SLAB + 2;
     // the delta = H tile of wave w: base index and whether the wave has one
     __host__ __device__ static constexpr int extra_base(int w) { return NB == 2 ? (w < NACT / 2 ? 0 : 1) : 0; }
     __host__ __device__ static constexpr bool has_extra(int w) { return NB == 2 ? true : w < NACT / 2; }
-    static constexpr size_t lds_bytes = ((size_t)2 * OM_SLAB * LD + PP) * 8;
+    static constexpr size_t lds_bytes = ((size_t)2 * OM_SLAB * LD + PP + (size_t)PP * DLD) * 8;
 };
 
 // row_shr:N within the 16 lanes of a DPP row, zero fill
@@ -868,103 +874,181 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
     const int g = lane >> 4;
     const double *Vw = V + ((g >> 1) + 8 * (g & 1)) * LD + (lane & 15) + 16 * NB * wave;
     const bool mfma_wave = wave < S::NACT;
-    const bool extra_on_b1 = S::extra_base(wave) == 1, extra = S::has_extra(wave);
 
-    // producer: lane = (column cs of 4, window wl of 16); column of slot q is q*32 + wave*4 + cs.
-    // address = (wave-uniform 64-bit base) + (32-bit lane offset): no per-column pointer registers
+    // Producer of the next slab's window sums.  Every vector instruction of a wave is paid in matrix-pipe time
+    // (profiles/r2_fp64_sustain_probe.txt), so the scan over the 16 windows of a slab is done where it is cheapest:
+    //   loads   lane = (column cs of 4, window wl of 16), 8 bytes a lane, coalesced; slot q covers the wave's columns
+    //           4q .. 4q+3 (a wave owns CW contiguous columns)
+    //   phase A d = x[t+len] - x[t] (olbm.c:61-62), one subtraction per slot, written to the wave's private LDS image
+    //           D[column][window]
+    //   phase B lane = (column c of CW, part h of NPART): reads its WPP consecutive differences back (16-byte reads),
+    //           sums them sequentially in registers -- one add per window instead of a 4-level DPP scan per element --
+    //           adds the running sum of the column and the totals of the parts before it, writes V (and the duplicate
+    //           columns) and keeps the new running sum.
+    // Round 1 ran the scan with DPP row shifts on the (column, window) lanes: ~25 vector instructions per slot and slab
+    // where this takes ~3.5.
+    constexpr int CW = S::CW, NPART = S::NPART, WPP = S::WPP, DLD = S::DLD;
+    double *D = om_sm + 2 * OM_SLAB * LD + PP + wave * (CW * DLD);
     const int cs = lane >> 4, wl = lane & 15;
     const unsigned lane_lo = (unsigned)((size_t)cs * n + wl), lane_hi = lane_lo + (unsigned)len;
-    double hi[NLD], lo[NLD], runq[NLD];
-#pragma unroll
-    for (int q = 0; q < NLD; q++) runq[q] = run[q * 4 * OM_NW + wave * 4 + cs];
-    // Raw loads through a buffer descriptor rebuilt per (slot, slab) in scalar registers: the hardware range
-    // check returns 0 past the end of x, so the load needs no branch and no per-lane address arithmetic.
-    // What it reads for columns >= p or for windows past the end is real memory of other columns: it only
-    // reaches rows/columns of V that the masks below and the finish kernel (row, col < p) discard.
-    const unsigned off_lo = lane_lo * 8u, off_hi = lane_hi * 8u;
+    double hi[NLD], lo[NLD];
+    const int pc = lane % CW, ph = lane / CW;            // phase B: column of the wave, part
+    const int pcol = wave * CW + pc;                     // global column
+    double runc = run[pcol];
+    // Raw loads through one buffer descriptor per slot, built once (base = the slot's first column at w_begin, extent =
+    // the rest of x): the hardware range check returns 0 past the end of x, so a load needs no branch, no per-lane
+    // address arithmetic and no scalar code -- the two lane offsets advance by one slab per slab (two VALU adds a slab;
+    // round 1 rebuilt the descriptors per slot and slab, ~25 dependent scalar instructions each).  What a load reads
+    // for columns >= p or for windows past the end is real memory of other columns: it only reaches rows/columns of V
+    // that the tail mask below and the finish kernel (row, col < p) discard.
+    unsigned off_lo = lane_lo * 8u, off_hi = lane_hi * 8u;
     const long total = (long)n * p;
-    auto load_q = [&](int q, long w0) {
-        const long first = (long)(q * 4 * OM_NW + wave * 4) * n + w0;          // uniform
+    __amdgpu_buffer_rsrc_t rs[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+        const long first = (long)(wave * CW + q * 4) * n + w_begin;          // uniform
         long rem = (total - first) * 8;
         rem = rem < 0 ? 0 : (rem > 0xffffffffL ? 0xffffffffL : rem);
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(x + (first < total ? first : 0)), 0, (int)(unsigned)rem, 0x00020000);
-        hi[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, off_hi, 0, 0));
-        lo[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, off_lo, 0, 0));
+        rs[q] = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (first < total ? first : 0)), 0, (int)(unsigned)rem, 0x00020000);
+    }
+    auto load_slab = [&]() {                 // the slab at the current offsets; then the offsets move on
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            hi[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs[q], off_hi, 0, 0));
+            lo[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs[q], off_lo, 0, 0));
+        }
+        off_hi += OM_SLAB * 8u;
+        off_lo += OM_SLAB * 8u;
     };
-    // window sums of slab w0 for slot q -> Vdst (and the duplicate columns).  Straight-line code (selects,
-    // no branches) so that the scheduler can spread it between the MFMAs of a k-step.
-    auto produce = [&](int q, long w0, double *Vdst) {
-        const double d = hi[q] - lo[q];
-        double inc = d;
-        inc += om_row_shr<1>(inc);
-        inc += om_row_shr<2>(inc);
-        inc += om_row_shr<4>(inc);
-        inc += om_row_shr<8>(inc);
-        const double excl = om_row_shr<1>(inc);
-        const double tot = __shfl(inc, lane | 15, 64);
-        const double vs = runq[q] + excl;
-        const bool valid = w0 + wl < w_end;
-        const double v = __hiloint2double(valid ? __double2hiint(vs) : 0, valid ? __double2loint(vs) : 0);
-        runq[q] += tot;
-        const int c = q * 4 * OM_NW + wave * 4 + cs;
-        Vdst[wl * LD + c] = v;
-        // duplicate columns: always / never by slot where that is known, else steered to the row's padding
-        if (q * 4 * OM_NW + (OM_NW - 1) * 4 < S::DUPC) Vdst[wl * LD + PP + c] = v;
-        else if (q * 4 * OM_NW < S::DUPC) Vdst[wl * LD + (q * 4 * OM_NW + wave * 4 < S::DUPC ? PP + c : PP + S::DUPC)] = v;
+    auto phase_a = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) D[(q * 4 + cs) * DLD + wl] = hi[q] - lo[q];
     };
+    double dv[WPP], base = 0.0;
+    auto phase_b_read = [&]() {
+        const double *dp = D + pc * DLD + ph * WPP;
+#pragma unroll
+        for (int k = 0; k < WPP; k += 2) {
+            const double2 t = *(const double2 *)(dp + k);
+            dv[k] = t.x;
+            dv[k + 1] = t.y;
+        }
+    };
+    double excl = 0.0;                       // total of the parts before this lane's (exclusive scan over NPART lanes)
+    auto phase_b_prefix = [&]() {
+#pragma unroll
+        for (int k = 1; k < WPP; k++) dv[k] += dv[k - 1];              // inclusive prefix of the part
+        if constexpr (NPART == 2) {
+            const double t = __shfl(dv[WPP - 1], lane - CW, 64);
+            excl = ph >= 1 ? t : 0.0;
+        } else if constexpr (NPART > 2) {                             // log-step inclusive scan, then shifted by one part
+            double incl = dv[WPP - 1];
+#pragma unroll
+            for (int d = 1; d < NPART; d <<= 1) {
+                const double t = __shfl(incl, lane - d * CW, 64);
+                incl += ph >= d ? t : 0.0;
+            }
+            const double t = __shfl(incl, lane - CW, 64);
+            excl = ph >= 1 ? t : 0.0;
+        }
+    };
+    // window sums of slab w0 -> Vdst: the window starting at w0 + i is the running sum (window w0) plus the differences
+    // BEFORE i; the slab's total carries the running sum to w0 + 16.  tail: the slab reaches past w_end (uniform), its
+    // windows there are zeroed
+    const int dupoff = pcol < S::DUPC ? PP : PP + S::DUPC - pcol;      // duplicate column, or the row's padding slot
+    const bool wave_dups = wave * CW < S::DUPC;                        // uniform: waves past the duplicated columns skip it
+    const int nwl = (int)(w_end - w_begin);                            // windows of this segment (32-bit: scalar compares)
+    auto phase_b_write = [&](int r0, double *Vdst) {                   // r0: first window of the slab, relative to w_begin
+        base = runc + excl;
+        double *rowp = Vdst + (ph * WPP) * LD + pcol;
+        if (r0 + OM_SLAB <= nwl) {
+#pragma unroll
+            for (int k = 0; k < WPP; k++) {
+                const double v = k == 0 ? base : base + dv[k - 1];
+                rowp[k * LD] = v;
+                if (wave_dups) rowp[k * LD + dupoff] = v;
+            }
+        } else {                                                       // the segment's last slab (or past it)
+            const int left = nwl - (r0 + ph * WPP);
+            const int nv = left < 0 ? 0 : (left > WPP ? WPP : left);
+#pragma unroll
+            for (int k = 0; k < WPP; k++) {
+                double v = k == 0 ? base : base + dv[k - 1];
+                v = k < nv ? v : 0.0;
+                rowp[k * LD] = v;
+                rowp[k * LD + dupoff] = v;
+            }
+        }
+        runc = __shfl(base + dv[WPP - 1], (NPART - 1) * CW + pc, 64);  // the window at r0 + 16: the next running sum
+    };
+    // the slab hand-over only concerns LDS: wait for this wave's LDS traffic, not for the global loads in flight
+    // (__syncthreads would also drain vmcnt and expose the HBM latency of the loads for the slab after next)
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-#pragma unroll
-    for (int q = 0; q < NLD; q++) load_q(q, w_begin);
-#pragma unroll
-    for (int q = 0; q < NLD; q++) produce(q, w_begin, V);
-#pragma unroll
-    for (int q = 0; q < NLD; q++) load_q(q, w_begin + OM_SLAB);
+    load_slab();
+    phase_a();
+    phase_b_read();
+    phase_b_prefix();
+    phase_b_write(0, V);
+    load_slab();
     __syncthreads();
 
     constexpr bool all_mfma = S::NACT == OM_NW;
+    constexpr int NKS = OM_SLAB / 4;
+    // fragments of a k-step: NFR for the circulant tiles, and for NB == 2 the two operands of the wave's delta = H tile,
+    // read at a wave-dependent offset (a select between registers would put vector instructions inside the MFMA group)
+    constexpr int NFX = S::NFR + (NB == 2 ? 2 : 0);
+    const int xoff = NB == 2 ? 16 * S::extra_base(wave) : 0;
+    auto read_frags = [&](const double *Vc, int ks, double *fr) {
+#pragma unroll
+        for (int i = 0; i < S::NFR; i++) fr[i] = Vc[2 * ks * LD + 16 * i];
+        if constexpr (NB == 2) {
+            fr[S::NFR] = Vc[2 * ks * LD + xoff];
+            fr[S::NFR + 1] = Vc[2 * ks * LD + xoff + 16 * H];
+        }
+    };
+    auto mfma_step = [&](const double *fr) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int dlt = 0; dlt < H; dlt++)
+                acc[b * H + dlt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[b], fr[b + dlt], acc[b * H + dlt], 0, 0, 0);
+        if constexpr (NB == 2)       // every wave has one
+            acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[S::NFR], fr[S::NFR + 1], acc[NB * H], 0, 0, 0);
+        else                         // waves without a delta = H tile compute one nobody reads
+            acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[0], fr[H], acc[NB * H], 0, 0, 0);
+    };
     int cur = 0;
-    for (long w0 = w_begin; w0 < w_end; w0 += OM_SLAB, cur ^= 1) {
+    for (int r0 = 0; r0 < nwl; r0 += OM_SLAB, cur ^= 1) {
         const double *Vc = Vw + cur * (OM_SLAB * LD);
         double *Vn = V + (cur ^ 1) * (OM_SLAB * LD);
+        // A slab = 4 k-steps of NS MFMAs, issued as whole groups; the producer's work for the next slab sits BETWEEN the
+        // groups as clusters (a switch between the fp64 matrix and vector instruction costs ~6 cycles; the even
+        // interleave of round 1 paid that 17 times a k-step), one step of its dependent chain per cluster so that every
+        // LDS round trip has an MFMA group to complete in:
+        //   after k-step 0: differences -> D, read-back issued, global loads of the slab after next (a slab and a half
+        //                   ahead of their use)
+        //   after k-step 1: prefix sums, part totals requested     after 2: base + sums -> V, next running sum
+        // The fragments of k-step ks+1 are requested just before the MFMAs of ks.
+        double fr[2][NFX];
+        const bool do_mfma = all_mfma || mfma_wave;
+        if (do_mfma) read_frags(Vc, 0, fr[0]);
 #pragma unroll
-        for (int ks = 0; ks < OM_SLAB / 4; ks++) {
-            if (all_mfma || mfma_wave) {
-                const double *Vk = Vc + 2 * ks * LD;
-                double fr[S::NFR];
-#pragma unroll
-                for (int i = 0; i < S::NFR; i++) fr[i] = Vk[16 * i];
-#pragma unroll
-                for (int b = 0; b < NB; b++)
-#pragma unroll
-                    for (int dlt = 0; dlt < H; dlt++)
-                        acc[b * H + dlt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[b], fr[b + dlt], acc[b * H + dlt], 0, 0, 0);
-                if constexpr (NB == 2) {     // every wave has one: operands picked by a wave-uniform select
-                    const double ea = extra_on_b1 ? fr[1] : fr[0], eb = extra_on_b1 ? fr[1 + H] : fr[H];
-                    acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea, eb, acc[NB * H], 0, 0, 0);
-                } else {                     // waves without a delta = H tile compute one nobody reads
-                    acc[NB * H] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[0], fr[H], acc[NB * H], 0, 0, 0);
-                }
+        for (int ks = 0; ks < NKS; ks++) {
+            if (do_mfma && ks + 1 < NKS) read_frags(Vc, ks + 1, fr[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_mfma) mfma_step(fr[ks & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) {
+                phase_a();
+                phase_b_read();
+                load_slab();                     // the slab after next: consumed by phase A of the next slab
             }
-            // a share of the next slab's production, and of the loads of the one after, rides in the shadow
-            // of this k-step's MFMAs: the matrix pipe runs an MFMA for 64 cycles while the wave issues on
-#pragma unroll
-            for (int q = 0; q < NLD; q++)
-                if (q * (OM_SLAB / 4) / NLD == ks && (NLD >= OM_SLAB / 4 || ks * NLD % (OM_SLAB / 4) == 0)) {
-                    produce(q, w0 + OM_SLAB, Vn);
-                    load_q(q, w0 + 2 * OM_SLAB);
-                }
-            if constexpr (all_mfma) {
-#pragma unroll
-                for (int i = 0; i < S::NS; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // a few VALU of the producer
-                    if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);   // an LDS op
-                    if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
-                }
-            }
+            if (ks == 1) phase_b_prefix();
+            if (ks == 2) phase_b_write(r0 + OM_SLAB, Vn);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        lds_barrier();
     }
     // partial[segment][wave][slot][reg][lane]
     if (mfma_wave) {
@@ -1060,7 +1144,7 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
         HIP_TRY(hipGetLastError());
     }
     const long nwin = n - len + 1;
-    if (p <= 256 && 8 * (3 * n + len + 64) < (1L << 32)) {      // 32-bit byte offsets in the matrix-core kernel
+    if (p <= 256 && 8 * (4 * n + len + 64) < (1L << 32)) {      // 32-bit byte offsets in the matrix-core kernel: 3 columns + a segment + len
         int rc;
         if (p <= 64) rc = launch_olbm_mfma<4>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
         else if (p <= 128) rc = launch_olbm_mfma<8>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
