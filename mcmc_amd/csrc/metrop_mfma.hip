@@ -6,7 +6,7 @@
 // chain-iteration, followed by n softplus evaluations per chain.
 //
 // Per Metropolis iteration two kernels run on the library stream:
-//   logdens_mfma_kernel  grid (ceil(C / 256), nsplit): a workgroup of MFMA_NW = 8 wavefronts (two per SIMD) owns 256
+//   logdens_mfma_kernel  grid (ceil(C / 256), observation splits): a workgroup of MFMA_NW = 8 wavefronts (two per SIMD) owns 256
 //       chains; wave w owns MFMA_NC = 2 tiles of 16 chains whose Theta fragments stay in VGPRs for the whole launch
 //       (loop invariant).  Every wave reads the X fragments of its share of the observation tiles straight from
 //       global memory into registers, one tile ahead (16-byte loads; all waves of a CU and all CUs of an XCD read the
@@ -18,15 +18,16 @@
 //       running sum: eta never leaves registers.  The epilogue of tile t runs as four clusters of vector
 //       instructions between the four MFMA groups of tile t+1 (TilePlan below: why clusters and not an even
 //       interleave).
-//   metrop_update_kernel one lane per chain: fixed-order sum of the nsplit partials, prior term, accept rule
+//   metrop_update_kernel one lane per chain: fixed-order sum of the per-unit partials, prior term, accept rule
 //       (metrop.c:225-235), state/batch-means bookkeeping, Philox normals and the next proposal.
 //
-// Reproducibility: a log density is the fixed-order sum of nsplit partial sums, and nsplit (make_plan) depends on
-// the number of chains of the CALL.  The same chains run as one call or sharded over calls / GPUs therefore see
-// log densities that can differ in the last bits (<= 1e-12 relative, tests/test_gpu_round2.py::
-// test_c3_bench_shape_logdens), and a decision with u within that distance of exp(delta) could differ; reruns
-// of the same call shape are bitwise reproducible.  The AUTO rule between the stream and MFMA paths also looks
-// at the chain count: a sharded run that must reproduce an unsharded one pins `path`.
+// Reproducibility: the observations are cut into units (at most 256, a function of the data alone: make_plan); the
+// density kernel writes one partial sum per (unit, chain), accumulated in a fixed order, and the update kernel adds the
+// units in order.  A log density therefore has the same bits whatever the number of chains of the call, the observation
+// split of the launch, or the number of calls / GPUs the chains are sharded over
+// (tests/test_gpu_round2.py::test_mfma_logdens_bits_do_not_depend_on_the_call_shape).  What can still differ between a
+// sharded and an unsharded run is the PATH: the AUTO rule between the stream and MFMA kernels looks at the chain
+// count, and the two kernels sum in different orders; a sharded run that must reproduce an unsharded one pins `path`.
 //
 // HBM layout: X is stored once per target as sign-folded fragment-major tiles
 //   xt[tile][kstep/2][lane][kstep%2] = s_row * X[16*tile + (lane&15)][4*kstep + (lane>>4)],  s = +1 (y==1) / -1 (y==0)
@@ -143,8 +144,8 @@ template <int KS, int NC, int NW, int TC>
 __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__restrict__ xt,
                                                                const double *__restrict__ prop, long ldc,
                                                                double *__restrict__ partial,
-                                                               long tiles_per_split, long ntiles,
-                                                               const SoftplusTables *__restrict__ tab)
+                                                               int tiles_per_unit, int units_per_split, int nunits,
+                                                               long ntiles, const SoftplusTables *__restrict__ tab)
 {
     using P = TilePlan<KS, NC>;
     constexpr int GK = P::GK, NG = P::NG, NV = P::NV, NP = P::npend();
@@ -165,14 +166,15 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         for (int c = 0; c < NC; c++)
             b[ks][c] = prop[(size_t)(4 * ks + (lane >> 4)) * ldc + chain0 + 16 * c + (lane & 15)];
 
-    const long t0 = (long)blockIdx.y * tiles_per_split;
-    long t1 = t0 + tiles_per_split;
-    if (t1 > ntiles) t1 = ntiles;
+    // The observations are cut into UNITS of tiles_per_unit tiles, a size that depends on the data alone (make_plan).
+    // One partial sum is written per (unit, chain), always accumulated in the same order, and the update kernel adds
+    // the units in order: a log density has the same bits whatever the number of chains of the call, the observation
+    // split of the launch or the number of GPUs the chains are sharded over.  A workgroup owns whole units.
+    const int u_begin = (int)blockIdx.y * units_per_split;
+    const int u_end = u_begin + units_per_split < nunits ? u_begin + units_per_split : nunits;
 
     const double sp_shift = softplus_lds_shift(sTab);
     double sum[NC];               // sum of M(eta) = |eta|/2 + L(|eta|)
-#pragma unroll
-    for (int c = 0; c < NC; c++) sum[c] = 0.0;
 
     __syncthreads();   // publishes the table
 
@@ -180,12 +182,6 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     // kernel), so only M(eta) = |eta|/2 + L(|eta|) is accumulated here
     double4_t acc2[2][NC];        // ping-pong accumulators: tile tt uses acc2[tt & 1]
     SoftplusRec pend[NP];         // table records of the pending values (an all-zero record evaluates to 0)
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int c = 0; c < NC; c++) acc2[i][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
     // a[]: this lane's X fragments of the tile about to be multiplied; tile_block refills each group's registers with
     // the NEXT tile's fragments (nx: this lane's column of it in global memory) as soon as the group has been issued,
@@ -269,13 +265,28 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     const std::true_type with_old;
     const std::false_type first_tile;
 
-    // tiles t0 .. t1-1: the first has no previous tile, then pairs (odd tile -> acc2[1], even -> acc2[0]).  The tile
-    // after the last is never needed: its loads are pointed at the last tile again (inside the allocation).
-    const int nt = (int)(t1 - t0);               // 32-bit tile counters: the scalar unit has no 64-bit ordered compare
-    if (nt > 0) {
+    for (int u = u_begin; u < u_end; u++) {
+        // a unit starts the pipeline afresh (first tile without a previous one, drain at the end): ~1000 cycles per
+        // unit of >= 2 * 2600 * tiles_per_unit
+#pragma unroll
+        for (int c = 0; c < NC; c++) sum[c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) acc2[i][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        // tiles t0 .. t0+nt-1: the first has no previous tile, then pairs (odd tile -> acc2[1], even -> acc2[0]).  The
+        // tile after the very last is never needed: its loads are pointed at the last tile again (inside the allocation).
+        const long t0 = (long)u * tiles_per_unit;
+        const long left = ntiles - t0;
+        const int nt = left < tiles_per_unit ? (int)left : tiles_per_unit;   // 32-bit tile counters: scalar compares
         const double *x0 = xt + (size_t)t0 * (KS * 64);
-        auto col = [&](int i) { return x0 + (size_t)(i < nt ? i : nt - 1) * (KS * 64); };
-        refill(col(0), 0, KS);
+        // the loads behind the unit's last tile fetch the first tile of the next unit of this workgroup (contiguous in
+        // memory), so only the first unit waits for its first fragments
+        const int lim = u + 1 < u_end ? nt : nt - 1;
+        auto col = [&](int i) { return x0 + (size_t)(i < lim ? i : lim) * (KS * 64); };
+        if (u == u_begin) refill(col(0), 0, KS);
         tile_block(col(1), acc2[0], acc2[1], first_tile);
         int i = 1;
         for (; i + 1 < nt; i += 2) {
@@ -288,15 +299,14 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         } else {
             drain(acc2[0], acc2[1]);
         }
-    }
-
-    // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
+        // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        double v = sum[c];                             // partial = sum(|eta|)/2 + sum(L); the update kernel negates
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < 16) partial[(size_t)blockIdx.y * ldc + chain0 + 16 * c + lane] = v;
+        for (int c = 0; c < NC; c++) {
+            double v = sum[c];                             // partial = sum(|eta|)/2 + sum(L); the update kernel negates
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) partial[(size_t)u * ldc + chain0 + 16 * c + lane] = v;
+        }
     }
 }
 
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 struct UpdParams {
     long nchain, ldc;
     int d, dpad;
-    int nsplit;
+    int nunits;             // partial sums per chain (one per unit of observations, added in order)
     double pad_term;        // npad_rows * ln 2 (each zero row contributes exactly -L(0))
     double prior_c;
     int nbatch, blen, nspac;
@@ -366,9 +376,9 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     const int d = q.d;
     const long ldc = q.ldc;
     // log density = sum_i [ (eta_i - |eta_i|)/2 - L(|eta_i|) ] - prior_c |theta|^2, with
-    // sum_i eta_i = colsum . theta (eta is linear in theta) and the rest from the MFMA kernel's partials
+    // sum_i eta_i = colsum . theta (eta is linear in theta) and the rest from the MFMA kernel's per-unit partials
     double part = 0.0;
-    for (int s = 0; s < q.nsplit; s++) part += q.partial[(size_t)s * ldc + c];
+    for (int s = 0; s < q.nunits; s++) part += q.partial[(size_t)s * ldc + c];
     double ss = 0.0, lin = 0.0;
     for (int j = 0; j < d; j++) {
         const double v = q.prop[(size_t)j * ldc + c];
@@ -454,8 +464,8 @@ __global__ void soa_init_kernel(const double *__restrict__ init, long nchain, in
 struct MfmaPlan {
     int ks, nc;
     long ldc, chain_blocks;
-    int nsplit;
-    long tiles_per_split;
+    int tiles_per_unit, nunits;      // functions of the target alone
+    int units_per_split, nsplit;     // how this call spreads the units over workgroups
 };
 
 static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
@@ -467,23 +477,24 @@ static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
     long per_wg = 16L * MFMA_NC * MFMA_NW;
     pl.chain_blocks = (nchain + per_wg - 1) / per_wg;
     pl.ldc = pl.chain_blocks * per_wg;
-    long chunks = t->ntiles / tc;
+    // units: at most 256 per target, at least two tile granules each (table load and B preload of a workgroup cost a
+    // few us).  Nothing here may depend on the chain count: the unit is the grain of the summation order.
+    long upt = (t->ntiles + 255) / 256;
+    upt = ((upt + tc - 1) / tc) * tc;
+    if (upt < 2L * tc) upt = 2L * tc;
+    pl.tiles_per_unit = (int)upt;
+    pl.nunits = (int)((t->ntiles + upt - 1) / upt);
     // one workgroup per CU (LDS-bound occupancy).  A grid that is a whole number of chip-fulls needs no
-    // observation split; otherwise split the observations until the tail round is small, keeping
-    // >= 2 chunks per workgroup (with 8 a 4096 x 5 posterior over 4096 chains ran on 32 workgroups).
+    // observation split; otherwise spread the units over workgroups until the tail round is small
+    // (with 8 splits a 4096 x 5 posterior over 4096 chains ran on 32 workgroups).
     // (Tried: an 8-way split decoded so that each XCD streams its own eighth of X.  The HBM-side read count did not
     // move -- an XCD then re-streams its eighth once per round of 32 workgroups, 8 rounds -- and the launch got 0.7 %
     // slower; the L2s request X from the fabric 8 to 16 times per launch either way, under 1 % of the HBM rate.)
     long want = 1;
-    if (pl.chain_blocks % num_cu != 0) {
-        want = (4L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;
-        long maxsplit = chunks / 2 > 0 ? chunks / 2 : 1;     // >= 2 chunks per workgroup (table load and B preload cost a few us)
-        if (want > maxsplit) want = maxsplit;
-        if (want > 256) want = 256;
-    }
-    long cps = (chunks + want - 1) / want;     // chunks per split
-    pl.nsplit = (int)((chunks + cps - 1) / cps);
-    pl.tiles_per_split = cps * tc;
+    if (pl.chain_blocks % num_cu != 0) want = (4L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;
+    if (want > pl.nunits) want = pl.nunits;
+    pl.units_per_split = (int)((pl.nunits + want - 1) / want);
+    pl.nsplit = (pl.nunits + pl.units_per_split - 1) / pl.units_per_split;
     return pl;
 }
 
@@ -493,7 +504,7 @@ static void launch_ld(const MfmaPlan &pl, const mcmchip_target *t, const double 
 {
     dim3 grid((unsigned)pl.chain_blocks, (unsigned)pl.nsplit), block(MFMA_NW * 64);
     hipLaunchKernelGGL((logdens_mfma_kernel<KS, MFMA_NC, MFMA_NW, TC>), grid, block, 0, dc->stream, t->xt, prop,
-                       pl.ldc, partial, pl.tiles_per_split, t->ntiles, dc->d_tables);
+                       pl.ldc, partial, pl.tiles_per_unit, pl.units_per_split, pl.nunits, t->ntiles, dc->d_tables);
 }
 
 static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const double *prop, double *partial,
@@ -558,7 +569,7 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     Workspace ws(dc);
     ws.want((size_t)t->dpad * ldc * 8);
     ws.want((size_t)t->dpad * ldc * 8);
-    ws.want((size_t)pl.nsplit * ldc * 8);
+    ws.want((size_t)pl.nunits * ldc * 8);
     ws.want((size_t)ldc * 8);
     ws.want((size_t)ldc * 8);
     ws.want((size_t)ldc * 8);
@@ -574,7 +585,7 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
 
     UpdParams q;
     memset(&q, 0, sizeof q);
-    q.nchain = p.nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nsplit = pl.nsplit;
+    q.nchain = p.nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nunits = pl.nunits;
     q.pad_term = (double)t->npad_rows * 0.6931471805599453;
     q.prior_c = t->prior_c;
     q.nbatch = p.nbatch; q.blen = p.blen; q.nspac = p.nspac;
@@ -628,7 +639,7 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
     DevBuf state, prop, partial;
     HIP_TRY(state.alloc((size_t)t->dpad * ldc * 8));
     HIP_TRY(prop.alloc((size_t)t->dpad * ldc * 8));
-    HIP_TRY(partial.alloc((size_t)pl.nsplit * ldc * 8));
+    HIP_TRY(partial.alloc((size_t)pl.nunits * ldc * 8));
     long total = (long)t->dpad * ldc;
     hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, states,
                        nchain, t->d, t->dpad, ldc, state.as<double>(), prop.as<double>());
@@ -640,7 +651,7 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
     if (rc) return rc;
     UpdParams q;
     memset(&q, 0, sizeof q);
-    q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nsplit = pl.nsplit;
+    q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nunits = pl.nunits;
     q.pad_term = (double)t->npad_rows * 0.6931471805599453;
     q.prior_c = t->prior_c;
     q.nbatch = q.blen = q.nspac = 1;
@@ -681,7 +692,7 @@ int launch_logdens_mfma_noalloc(const mcmchip_target *t, const double *states, l
     hipStream_t s = dc->stream;
     const MfmaPlan pl = make_plan(t, nchain, dc->num_cu);          // the plan of mcmchip_logdens: same bits
     const long ldc = pl.ldc;
-    const size_t nprop = (size_t)t->dpad * ldc, npart = (size_t)pl.nsplit * ldc;
+    const size_t nprop = (size_t)t->dpad * ldc, npart = (size_t)pl.nunits * ldc;
     if (nprop + npart > (size_t)MCMCHIP_NOALLOC_SCRATCH_DOUBLES)
         return set_error(MCMCHIP_ECAP, "mcmchip_logdens_noalloc: %ld chains of dimension %d need %zu doubles of scratch, the "
                          "fixed array holds %ld (use mcmchip_logdens)", nchain, t->d, nprop + npart, (long)MCMCHIP_NOALLOC_SCRATCH_DOUBLES);
@@ -693,7 +704,7 @@ int launch_logdens_mfma_noalloc(const mcmchip_target *t, const double *states, l
     if (int rc = launch_logdens(pl, t, prop, partial, dc)) return rc;
     UpdParams q;
     memset(&q, 0, sizeof q);
-    q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nsplit = pl.nsplit;
+    q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nunits = pl.nunits;
     q.pad_term = (double)t->npad_rows * 0.6931471805599453;
     q.prior_c = t->prior_c;
     q.nbatch = q.blen = q.nspac = 1;

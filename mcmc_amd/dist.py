@@ -4,10 +4,10 @@
 The path shards by independent units -- chains (metrop) or ensembles (temper): rank r owns a
 contiguous block, X/y/scale are replicated, and Philox streams are keyed by the GLOBAL chain id
 (args.chain_offset), so every chain draws the same random numbers whatever the number of GPUs.
-On the stream path and in temper the whole trajectory is then identical; on the MFMA path the
-observation split of the log-density sum follows the chains per call, so log densities agree
-to <= 1e-12 relative across shardings (a decision could differ only at such a tie) -- callers that
-need one path for all shardings pin `path`, since the AUTO rule looks at the chain count.  There is NO
+The whole trajectory of a chain is then identical for any sharding, on the stream path, in temper and on
+the MFMA path alike (the MFMA kernel sums the observations in units that depend on the data alone).  The
+one thing that looks at the chain count is the AUTO rule between the two metrop kernels, which sum in
+different orders: callers that need bit-identical results across shardings pin `path`.  There is NO
 per-iteration communication; the only collective is one all-gather of the batch means and
 acceptance rates at the end.  The reference has no counterpart (it runs one
 chain in one process).

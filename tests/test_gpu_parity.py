@@ -232,7 +232,9 @@ def _synthetic(n, d, seed=42):
 
 
 @pytest.mark.parametrize("n,d,C", [(20000, 64, 256), (5003, 5, 100), (8192, 20, 300), (4099, 33, 64),
-                                   (6007, 65, 70), (4099, 100, 64), (8192, 128, 300), (33, 96, 5)])   # d > 64: one tile per chunk
+                                   (6007, 65, 70), (4099, 100, 64), (8192, 128, 300), (33, 96, 5),    # d > 64: one tile per chunk
+                                   (5000, 32, 64), (3000, 48, 70), (3000, 56, 70), (7, 100, 3), (17, 70, 3),
+                                   (300000, 64, 40)])                # several units per workgroup
 def test_logdens_mfma_vs_oracle(api, oracle_mod, n, d, C):
     X, y, beta = _synthetic(n, d, seed=n)
     states = beta + 0.3 * np.random.default_rng(1).standard_normal((C, d))

@@ -677,3 +677,30 @@ def test_time_sharded_initseq_and_olbm_device_route(api, oracle_mod):
     assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))
     v1, m1 = mdist.olbm_sharded(lambda xb, l, m: api.olbm_device(xb, l, mean=m)[0], xd, n, blen)
     assert np.max(np.abs(v1 - ref)) <= 1e-10 * np.max(np.abs(ref)) and np.allclose(m1, mean, rtol=1e-13)
+
+
+def test_mfma_logdens_bits_do_not_depend_on_the_call_shape(api):
+    """ADVICE (round 1): the observation split followed the chain count of the call, so resharding moved log densities
+    in the last bits.  The partial sums are now per unit of observations (a function of the data alone): the same state
+    has the same log density, bit for bit, in a call of 3, 64, 300 or 4096 chains, and a sharded Philox run equals the
+    unsharded one on the MFMA path."""
+    from mcmc_amd import abi
+    rng = np.random.default_rng(12)
+    n, d = 70_000, 20
+    X = rng.standard_normal((n, d)); X[:, 0] = 1.0
+    beta = 0.3 * rng.standard_normal(d)
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    tg = api.logistic_target(X, y)
+    states = beta + 0.05 * rng.standard_normal((4096, d))
+    full = api.logdens(tg, states, path=abi.PATH_MFMA)
+    for C in (3, 64, 300, 1025):
+        part = api.logdens(tg, states[:C], path=abi.PATH_MFMA)
+        assert np.array_equal(part, full[:C]), C
+    tail = api.logdens(tg, states[4000:], path=abi.PATH_MFMA)
+    assert np.array_equal(tail, full[4000:])
+    # a Philox run sharded 3 ways (ragged) against the unsharded run, MFMA path pinned
+    init = states[:700]
+    whole = api.metrop(tg, init, 5, blen=2, scale=0.02, seed=5, path=abi.PATH_MFMA)
+    for lo, hi in ((0, 256), (256, 300), (300, 700)):
+        sh = api.metrop(tg, init[lo:hi], 5, blen=2, scale=0.02, seed=5, chain_offset=lo, path=abi.PATH_MFMA)
+        assert np.array_equal(sh["batch"], whole["batch"][lo:hi]) and np.array_equal(sh["final"], whole["final"][lo:hi])
