@@ -4,10 +4,12 @@
 The path shards by independent units -- chains (metrop) or ensembles (temper): rank r owns a
 contiguous block, X/y/scale are replicated, and Philox streams are keyed by the GLOBAL chain id
 (args.chain_offset), so every chain draws the same random numbers whatever the number of GPUs.
-The whole trajectory of a chain is then identical for any sharding, on the stream path, in temper and on
-the MFMA path alike (the MFMA kernel sums the observations in units that depend on the data alone).  The
-one thing that looks at the chain count is the AUTO rule between the two metrop kernels, which sum in
-different orders: callers that need bit-identical results across shardings pin `path`.  There is NO
+In temper and on metrop's MFMA path (which sums the observations in units that depend on the data alone)
+the whole trajectory of a chain is then identical for any sharding.  Two things look at the chain count of
+a call: the AUTO rule between the two metrop kernels and, on the stream path, the number of lanes that
+share a chain's observations (its cross-lane sum rounds differently for 16 and 64 lanes); log densities
+then agree to rounding (<= 1e-12 relative) and a decision could differ only at such a tie.  Callers that
+need bit-identical results across shardings pin `path` to the MFMA kernel.  There is NO
 per-iteration communication; the only collective is one all-gather of the batch means and
 acceptance rates at the end.  The reference has no counterpart (it runs one
 chain in one process).
