@@ -90,6 +90,9 @@ def main():
                     help="strong: --chains split over the GPUs (default for --gpus > 1); weak: --chains per GPU")
     ap.add_argument("--scale", type=float, default=4.0e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the collectives go through "
+                         "gloo on host copies (RCCL refuses two ranks on one device); exercises the sharding, not the fabric")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,14 +100,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if a.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # launched by torch.distributed.run
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)              # "nccl" is RCCL on ROCm
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
 
     from mcmc_amd import abi, api
-    api.init(local_rank)
+    api.init(dev_index)
     L = api.load_library()
 
     scaling = a.scaling or ("strong" if world > 1 else "weak")
@@ -143,9 +150,10 @@ def main():
             raise RuntimeError(L.mcmchip_last_error().decode())
         summ = torch.cat([out_accept.sum().reshape(1), out_batch.sum(dim=(0, 1)) / nbatch])     # sums over local chains
         if use_dist:
-            allsum = [torch.empty_like(summ) for _ in range(world)]
-            dist.all_gather(allsum, summ)
-            summ = torch.stack(allsum).sum(dim=0)
+            src = summ.cpu() if a.rehearse_on_one_gpu else summ
+            allsum = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(allsum, src)
+            summ = torch.stack(allsum).sum(dim=0).to(dev)
         return summ / total_chains, out_final[slot], int(out.iter_offset_out)
 
     def barrier():
@@ -154,8 +162,9 @@ def main():
         torch.cuda.synchronize()
 
     if use_dist:                                        # create the RCCL communicator outside the timed region
-        warm = [torch.empty(1 + d, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(warm, torch.zeros(1 + d, dtype=torch.float64, device=dev))
+        cdev = "cpu" if a.rehearse_on_one_gpu else dev
+        warm = [torch.empty(1 + d, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(warm, torch.zeros(1 + d, dtype=torch.float64, device=cdev))
     # warmup (untimed): the same call path as the timed region, collective and summary kernels included
     state, off = init, 0
     if a.warmup > 0:
@@ -167,7 +176,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if a.rehearse_on_one_gpu else dev))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -704,3 +704,34 @@ def test_mfma_logdens_bits_do_not_depend_on_the_call_shape(api):
     for lo, hi in ((0, 256), (256, 300), (300, 700)):
         sh = api.metrop(tg, init[lo:hi], 5, blen=2, scale=0.02, seed=5, chain_offset=lo, path=abi.PATH_MFMA)
         assert np.array_equal(sh["batch"], whole["batch"][lo:hi]) and np.array_equal(sh["final"], whole["final"][lo:hi])
+
+
+def test_bench_two_rank_strong_split_rehearsal():
+    """bench.py launched as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with two ranks
+    sharing this box's one GPU (`--rehearse-on-one-gpu`: cuda:0 for every rank, gloo on host copies for the collectives):
+    the strong split of the job's 65 536 chains, the global chain ids of the Philox streams and initial states, the
+    summary all-gather and the max-over-ranks timing all run; the job accepts exactly as many proposals as the one-rank run
+    (the chains do not know how they were sharded)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--rehearse-on-one-gpu"] + common,
+                         capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                         timeout=200, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "strong" and r2["config"]["chains_per_gpu"] == 32768
+    assert r2["config"]["chains_total"] == r1["config"]["chains_total"] == 65536
+    # the same accept decisions chain by chain; the job's rate is a sum of per-chain rates (thirds at 3 steps) taken per
+    # rank and then over ranks, so only its rounding may differ
+    acc2, acc1 = r2["config"]["accept_rate"] * 65536 * 3, r1["config"]["accept_rate"] * 65536 * 3
+    assert abs(acc2 - acc1) < 1e-6 and abs(acc1 - round(acc1)) < 1e-6
+    assert r2["value"] > 0 and r2["roofline"]["frac"] > 0       # two ranks share one GPU here: no rate is asserted
