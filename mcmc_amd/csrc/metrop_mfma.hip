@@ -489,7 +489,11 @@ static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
     // (with 8 splits a 4096 x 5 posterior over 4096 chains ran on 32 workgroups).
     // (Tried: an 8-way split decoded so that each XCD streams its own eighth of X.  The HBM-side read count did not
     // move -- an XCD then re-streams its eighth once per round of 32 workgroups, 8 rounds -- and the launch got 0.7 %
-    // slower; the L2s request X from the fabric 8 to 16 times per launch either way, under 1 % of the HBM rate.)
+    // slower; the L2s request X from the fabric 8 to 16 times per launch either way, under 1 % of the HBM rate.
+    // Also tried: one round of workgroups, each walking its XCD's units for 8 chain blocks so that a unit of X (2 MB)
+    // is re-read from the L2 -- Theta (33 MB at C3) then has to be reloaded per (unit, chain block) and crosses the
+    // fabric once per unit: 7.1 GB instead of 4.1 GB, and 0.7 % slower.  Theta in registers for the whole launch and
+    // X streamed once per XCD is the cheaper side of that trade.)
     long want = 1;
     if (pl.chain_blocks % num_cu != 0) want = (4L * num_cu + pl.chain_blocks - 1) / pl.chain_blocks;
     if (want > pl.nunits) want = pl.nunits;
