@@ -100,8 +100,9 @@ template <int KIND> static void run(const char *name, int blocks, int threads, i
     hipFree(out); hipFree(clk); free(h);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int mult = argc > 1 ? atoi(argv[1]) : 1;      // run-length multiplier: does the rate hold over 100+ ms?
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     int ncu = p.multiProcessorCount, wall_khz = 0;
@@ -110,9 +111,9 @@ int main()
     const int used[] = {ncu, 8};
     for (int u = 0; u < 2; u++)
         for (int t = 256; t <= 1024; t *= 2) {
-            run<0>("mfma", used[u], t, 40000 * 256 / t, wall_khz);
-            run<1>("fma", used[u], t, 20000 * 256 / t, wall_khz);
-            if (u == 0) {
+            run<0>("mfma", used[u], t, mult * 40000 * 256 / t, wall_khz);
+            run<1>("fma", used[u], t, mult * 20000 * 256 / t, wall_khz);
+            if (u == 0 && mult == 1) {
                 run<41>("mfma 1 acc", used[u], t, 40000 * 256 / t, wall_khz);
                 run<42>("mfma 2 acc", used[u], t, 40000 * 256 / t, wall_khz);
                 run<43>("mfma 3 acc", used[u], t, 40000 * 256 / t, wall_khz);

@@ -74,7 +74,7 @@ int main()
     }
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
-    int ncu = p.multiProcessorCount, iters = 4000;
+    int ncu = p.multiProcessorCount, iters = 120000;     // >= 15 ms per kernel: shorter runs read the clock ramp (profiles/r2_fp64_sustain_probe.txt)
     double *out;
     hipMalloc(&out, (size_t)ncu * 2 * 256 * 8);
     for (int kind = 0; kind < 2; kind++)
