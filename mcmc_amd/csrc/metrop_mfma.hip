@@ -122,8 +122,8 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 // 32 switches a tile.  Here a tile is MFMA groups of GK k-steps (GK * NC instructions) separated by VALU clusters:
 //     cluster q (after group q-1): evaluate the values whose table records were requested one cluster ago,
 //                                  form the table addresses of the next values (softplus.h: 6 + 3 instructions a value)
-//     then issue the LDS reads those addresses need, and the X fragments of the group after next: both have a whole
-//     MFMA group (>= 256 cycles) to land, so no s_waitcnt of the loop ever waits.
+//     then (behind the first k-step of the next group) issue the LDS reads those addresses need: they have the rest of
+//     the group (>= 256 cycles) to land; behind each group its X registers are refilled with the next tile's fragments.
 // The values of the last cluster have nothing behind them to hide their table reads: they stay pending (their eta in
 // the accumulator registers, which the tile after next only overwrites with its first MFMA; their records in `pend`)
 // and are evaluated in cluster 0 of the next tile.
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         auto mfma_ks = [&](int ks) {
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
+                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
         };
 #pragma unroll
         for (int g = 0; g < NG; g++) {
