@@ -12,7 +12,9 @@
 //   p <= 256: olbm_mfma_kernel, all columns in one workgroup, var = V^T V on v_mfma_f64_16x16x4_f64 with
 //   the window sums V rebuilt on the fly (see the comment at the kernel).  Window sums are seeded per
 //   time segment by a direct centred sum, so rounding does not accumulate along n as in the reference's
-//   running recurrence (olbm.c:61-62).
+//   running recurrence (olbm.c:61-62).  Means not supplied and n >= 2^20: no separate pass for the means
+//   (olbm.c:38-43); the window sums are taken about a provisional centre, the exact means come out of them and
+//   the matrix is corrected by a rank-two term (see pilot_centre_kernel).
 //   p > 256: olbm_kernel, one workgroup per 64 x 64 tile pair of the lower triangle, 4 x 4 outputs per
 //   lane in registers.
 #include "kernels.h"
@@ -786,6 +788,9 @@ __global__ void olbm_finish_kernel(const double *__restrict__ partial, long nseg
 // at (one base register) + (compile-time offset) and a k-step costs NB + F/2 ds_read_b64 for its MFMAs.
 #define OM_SLAB 16
 #define OM_NW 8
+#define OL_ONEPASS_MIN_N (1L << 20)      // shorter series: the means come from colsum_kernel first, as in olbm.c:38-43
+#define OL_PILOT_RUNS 4096               // runs of 8 rows in the provisional centre's sample
+#define OL_ONEPASS_MAX_LOSS 1.0e3        // repeat about the exact mean if the correction would cost more than 3 digits
 
 typedef double om_double4 __attribute__((ext_vector_type(4)));
 
@@ -825,8 +830,9 @@ template <int N> __device__ __forceinline__ double om_row_shr(double v)
 template <int F>
 __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__restrict__ x, long n, int p, long len,
                                                                long nwin, long seg_windows,
-                                                               const double *__restrict__ mean,
-                                                               double *__restrict__ partial)
+                                                               const double *__restrict__ centre,
+                                                               double *__restrict__ partial,
+                                                               double *__restrict__ colpart)
 {
     using S = OmShape<F>;
     constexpr int LD = S::LD, PP = S::PP, H = S::H, NB = S::NB, NLD = S::NLD;
@@ -849,7 +855,7 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
             for (int u = 0; u < 4; u++) {
                 const int c = c0 + u * OM_NW < p ? c0 + u * OM_NW : c0;     // clamp: the duplicate is dropped below
                 xc[u] = x + (size_t)c * n + w_begin;
-                m4[u] = mean[c];
+                m4[u] = centre[c];
             }
 #pragma unroll 4
             for (long q = lane; q < len; q += 64)
@@ -920,6 +926,7 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
         off_hi += OM_SLAB * 8u;
         off_lo += OM_SLAB * 8u;
     };
+    const int nwl = (int)(w_end - w_begin);                            // windows of this segment (32-bit: scalar compares)
     auto phase_a = [&]() {
 #pragma unroll
         for (int q = 0; q < NLD; q++) D[(q * 4 + cs) * DLD + wl] = hi[q] - lo[q];
@@ -957,7 +964,19 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
     // windows there are zeroed
     const int dupoff = pcol < S::DUPC ? PP : PP + S::DUPC - pcol;      // duplicate column, or the row's padding slot
     const bool wave_dups = wave * CW < S::DUPC;                        // uniform: waves past the duplicated columns skip it
-    const int nwl = (int)(w_end - w_begin);                            // windows of this segment (32-bit: scalar compares)
+    // For the one-pass route (see pilot_centre_kernel): the windows 0, len, 2 len, ... tile the series, so their sums about
+    // the centre add up to n * (mean - centre) less a tail of < len rows: the exact mean comes out of the window sums,
+    // without a pass over x and without cancellation.  Such a window comes by once in len windows; its sum is added to
+    // the column's slot of run[] (the seeds there are spent, and a column belongs to one wave, whose LDS operations
+    // stay in order).  next_sel: the next such window, relative to w_begin.
+    auto fresh_lane = [&]() {
+        int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    if (ph == 0) run[pcol] = 0.0;
+    int next_sel = (int)((len - w_begin % len) % len);
+    if ((long)next_sel >= (long)nwl) next_sel = 0x7fffffff;
     auto phase_b_write = [&](int r0, double *Vdst) {                   // r0: first window of the slab, relative to w_begin
         base = runc + excl;
         double *rowp = Vdst + (ph * WPP) * LD + pcol;
@@ -978,6 +997,15 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
                 rowp[k * LD] = v;
                 rowp[k * LD + dupoff] = v;
             }
+        }
+        while (next_sel < r0 + OM_SLAB) {                              // uniform, once in len windows
+            // read back from the slab just written (the same wave wrote it; zero past the end of the segment).  The lane
+            // index is taken afresh from the hardware: nothing lane-dependent of this rare path may stay live across
+            // the slab loop, which has no register to spare (a spill there reloads through the vector memory queue,
+            // behind the loads for the slab after next)
+            const int l2 = fresh_lane();
+            if (l2 < CW) run[wave * CW + l2] += Vdst[(next_sel - r0) * LD + wave * CW + l2];
+            next_sel = len >= (long)(nwl - next_sel) ? 0x7fffffff : next_sel + (int)len;
         }
         runc = __shfl(base + dv[WPP - 1], (NPART - 1) * CW + pc, 64);  // the window at r0 + 16: the next running sum
     };
@@ -1050,6 +1078,11 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
         }
         lds_barrier();
     }
+    // colpart[segment][column]: the windows at multiples of len
+    {
+        const int l2 = fresh_lane();
+        if (l2 < CW) colpart[(size_t)blockIdx.x * PP + wave * CW + l2] = run[wave * CW + l2];
+    }
     // partial[segment][wave][slot][reg][lane]
     if (mfma_wave) {
         double *out = partial + ((size_t)blockIdx.x * S::NACT + wave) * S::NS * 256;
@@ -1062,9 +1095,81 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
 
 // one workgroup per (wave, slot) tile: sums the segments in order, scales (olbm.c:74) and mirrors (olbm.c:75).
 // accumulator layout of v_mfma_f64_16x16x4: register r of lane l holds D[row = l/16 + 4r][col = l % 16]
+// One-pass route (means not supplied, long series): the main kernel centres the window sums about a PROVISIONAL centre
+// c (pilot_centre_kernel: a thin, evenly spread sample of the series) and collects the column sums S' of its window
+// sums V' = W - len*c, and the sums over the windows 0, len, 2 len, ... alone, which tile the series and so give the
+// exact mean m = c + (their sum + a tail of < len rows) / n.  With delta = m - c
+// and V = W - len*m = V' - len*delta, the matrix olbm.c:52-75 accumulates is
+//     sum_w V V^T = sum_w V' V'^T - len (S' delta^T + delta S'^T) + nwin len^2 delta delta^T,
+// so the separate pass over x that computed the means first (a quarter of the HBM traffic of the whole call) is gone.
+// The correction cancels against the main term by a factor 1 + nwin len^2 delta_c^2 / (sum_w V_c^2); the caller checks
+// that factor and, should a sample ever miss the mean that badly, repeats the kernel about the exact mean.
+__global__ __launch_bounds__(256) void pilot_centre_kernel(const double *__restrict__ x, long n, int runs,
+                                                           double *__restrict__ centre)
+{
+    __shared__ double red[4];
+    const double *xc = x + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < runs; r += 256) {
+        const long t0 = ((long)r * (n - 8)) / (runs - 1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += xc[t0 + k];
+    }
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) centre[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) / (8.0 * runs);
+}
+
+// one workgroup per column: delta = mean - centre from the tiling windows and the < len rows after the last of them;
+// vtot = S', the column sum of all window sums about the centre = sum_t cnt(t) (x_t - c) with cnt(t) = the number of
+// windows that hold row t = min(t + 1, len, n - t, nwin): len n delta less what the rows near the two ends fall short
+__global__ __launch_bounds__(256) void olbm_centre_finish_kernel(const double *__restrict__ x, long n, long len,
+                                                                 const double *__restrict__ colpart, long nseg, int PP,
+                                                                 const double *__restrict__ centre,
+                                                                 double *__restrict__ mean, double *__restrict__ delta,
+                                                                 double *__restrict__ vtot)
+{
+    __shared__ double red[2][4];
+    const int col = blockIdx.x;
+    const double c = centre[col];
+    const long nwin = n - len + 1;
+    double st = 0.0, sv = 0.0;
+    for (long g = threadIdx.x; g < nseg; g += 256) st += colpart[(size_t)g * PP + col];
+    const double *xc = x + (size_t)col * n;
+    for (long t = (n / len) * len + threadIdx.x; t < n; t += 256) st += xc[t] - c;
+    // rows held by fewer than len windows: the first and the last len rows (all rows if they overlap)
+    const long head = len < n ? len : n, tail0 = n - len > head ? n - len : head;
+    for (long i = threadIdx.x; i < head + (n - tail0); i += 256) {
+        const long t = i < head ? i : tail0 + (i - head);
+        long cnt = t + 1 < len ? t + 1 : len;
+        cnt = n - t < cnt ? n - t : cnt;
+        cnt = nwin < cnt ? nwin : cnt;
+        sv += (double)(len - cnt) * (xc[t] - c);
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+        st += __shfl_xor(st, m, 64);
+        sv += __shfl_xor(sv, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = st;
+        red[1][threadIdx.x >> 6] = sv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nd = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];        // n * delta
+        const double d = nd / (double)n;
+        delta[col] = d;
+        mean[col] = c + d;                                             // olbm.c:42
+        vtot[col] = (double)len * nd - (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]);
+    }
+}
+
 template <int F>
 __global__ __launch_bounds__(256) void olbm_mfma_finish_kernel(const double *__restrict__ partial, long nseg, int p,
-                                                               double denom, double *__restrict__ var)
+                                                               double denom, double *__restrict__ var,
+                                                               const double *__restrict__ delta,
+                                                               const double *__restrict__ vtot, double len, double nwin)
 {
     using S = OmShape<F>;
     const int w = blockIdx.x / S::NS, q = blockIdx.x % S::NS, e = threadIdx.x, r = e >> 6, l = e & 63;
@@ -1079,15 +1184,24 @@ __global__ __launch_bounds__(256) void olbm_mfma_finish_kernel(const double *__r
     for (long gseg = 0; gseg < nseg; gseg++) s += partial[(((size_t)gseg * S::NACT + w) * S::NS + q) * 256 + e];
     const int row = 16 * fa + (l >> 4) + 4 * r, col = 16 * fb + (l & 15);
     if (row < p && col < p) {
+        if (delta) {
+            // (row, col) and (col, row) of a diagonal tile are computed by different lanes and must agree bit for bit
+            // whatever the compiler contracts: both evaluate the expression of the ordered pair (a <= b)
+            const int a = row < col ? row : col, b = row < col ? col : row;
+            const double da = delta[a], db = delta[b];
+            s = s - len * (vtot[a] * db + da * vtot[b]) + nwin * len * len * da * db;
+        }
         const double v = s / denom;
         var[row + (size_t)p * col] = v;
         var[col + (size_t)p * row] = v;
     }
 }
 
+// dcentre: what the window sums are centred about.  dmean_out == nullptr: dcentre is the exact mean (supplied, or from
+// colsum_kernel).  Otherwise dcentre is provisional and the exact means go to dmean_out, delta = mean - centre to ddelta.
 template <int F>
-static int launch_olbm_mfma(const double *x, long n, int p, long len, long nwin, const double *dmean, double *dvar,
-                            DeviceCtx *dc)
+static int launch_olbm_mfma(const double *x, long n, int p, long len, long nwin, const double *dcentre, double *dmean_out,
+                            double *ddelta, double *dvar, DeviceCtx *dc)
 {
     using S = OmShape<F>;
     hipStream_t s = dc->stream;
@@ -1107,17 +1221,25 @@ static int launch_olbm_mfma(const double *x, long n, int p, long len, long nwin,
     if (seg < 16L * OM_SLAB) seg = 16L * OM_SLAB;
     seg = ((seg + OM_SLAB - 1) / OM_SLAB) * OM_SLAB;
     const long nseg = (nwin + seg - 1) / seg;
-    DevBuf part;
+    DevBuf part, colpart, vtot;
     HIP_TRY(part.alloc((size_t)nseg * S::NACT * S::NS * 256 * 8));
+    HIP_TRY(colpart.alloc((size_t)nseg * S::PP * 8));
+    HIP_TRY(vtot.alloc((size_t)p * 8));
     timing_reset("olbm_mfma_kernel");
     timing_begin(s);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nseg), dim3(64 * OM_NW), S::lds_bytes, s, x, n, p, len, nwin, seg, dmean,
-                       part.as<double>());
+    hipLaunchKernelGGL(kern, dim3((unsigned)nseg), dim3(64 * OM_NW), S::lds_bytes, s, x, n, p, len, nwin, seg, dcentre,
+                       part.as<double>(), colpart.as<double>());
     timing_end(s);
     HIP_TRY(hipGetLastError());
+    if (dmean_out) {
+        hipLaunchKernelGGL(olbm_centre_finish_kernel, dim3((unsigned)p), dim3(256), 0, s, x, n, len,
+                           colpart.as<double>(), nseg, S::PP, dcentre, dmean_out, ddelta, vtot.as<double>());
+        HIP_TRY(hipGetLastError());
+    }
     const double denom = (double)nwin * (double)n * (double)len;
     hipLaunchKernelGGL(olbm_mfma_finish_kernel<F>, dim3((unsigned)(S::NACT * S::NS)), dim3(256), 0, s,
-                       part.as<double>(), nseg, p, denom, dvar);
+                       part.as<double>(), nseg, p, denom, dvar, dmean_out ? ddelta : (const double *)nullptr,
+                       vtot.as<double>(), (double)len, (double)nwin);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));       // part is released on return
     return MCMCHIP_OK;
@@ -1127,11 +1249,21 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
 {
     hipStream_t s = dc->stream;
     if (n >= (1L << 31)) return set_error(MCMCHIP_EINVAL, "olbm: n exceeds the reference's int range (olbm.c:25)");
-    DevBuf dmean, dvar, part, cpart;
+    DevBuf dmean, dvar, part, cpart, dcentre, ddelta;
     HIP_TRY(dmean.alloc((size_t)p * 8));
     HIP_TRY(dvar.alloc((size_t)p * p * 8));
+    const long nwin = n - len + 1;
+    const bool mfma_route = p <= 256 && 8 * (4 * n + len + 64) < (1L << 32);   // 32-bit byte offsets in the matrix-core kernel: 3 columns + a segment + len
+    // one pass over x when the means are not supplied and the series is long enough for a second pass to matter
+    const bool one_pass = mfma_route && !nocalc && n >= OL_ONEPASS_MIN_N;
     if (nocalc) {
         HIP_TRY(hipMemcpyAsync(dmean.p, mean, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    } else if (one_pass) {
+        HIP_TRY(dcentre.alloc((size_t)p * 8));
+        HIP_TRY(ddelta.alloc((size_t)p * 8));
+        hipLaunchKernelGGL(pilot_centre_kernel, dim3((unsigned)p), dim3(256), 0, s, x, n, OL_PILOT_RUNS,
+                           dcentre.as<double>());
+        HIP_TRY(hipGetLastError());
     } else {
         const long chunk = 1 << 20;
         const long nchunk = (n + chunk - 1) / chunk;
@@ -1143,16 +1275,34 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
                            n, p, dmean.as<double>());
         HIP_TRY(hipGetLastError());
     }
-    const long nwin = n - len + 1;
-    if (p <= 256 && 8 * (4 * n + len + 64) < (1L << 32)) {      // 32-bit byte offsets in the matrix-core kernel: 3 columns + a segment + len
-        int rc;
-        if (p <= 64) rc = launch_olbm_mfma<4>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
-        else if (p <= 128) rc = launch_olbm_mfma<8>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
-        else rc = launch_olbm_mfma<16>(x, n, p, len, nwin, dmean.as<double>(), dvar.as<double>(), dc);
+    if (mfma_route) {
+        auto launch = [&](const double *centre, double *mean_out) {
+            if (p <= 64) return launch_olbm_mfma<4>(x, n, p, len, nwin, centre, mean_out, ddelta.as<double>(), dvar.as<double>(), dc);
+            if (p <= 128) return launch_olbm_mfma<8>(x, n, p, len, nwin, centre, mean_out, ddelta.as<double>(), dvar.as<double>(), dc);
+            return launch_olbm_mfma<16>(x, n, p, len, nwin, centre, mean_out, ddelta.as<double>(), dvar.as<double>(), dc);
+        };
+        int rc = one_pass ? launch(dcentre.as<double>(), dmean.as<double>()) : launch(dmean.as<double>(), nullptr);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(var, dvar.p, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
         if (!nocalc) HIP_TRY(hipMemcpyAsync(mean, dmean.p, (size_t)p * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (one_pass) {
+            // digits the centre correction cancelled: 1 + nwin len^2 delta_c^2 / (sum_w V_c^2), worst column
+            std::vector<double> hd((size_t)p);
+            HIP_TRY(hipMemcpy(hd.data(), ddelta.p, (size_t)p * 8, hipMemcpyDeviceToHost));
+            bool redo = false;
+            for (int c = 0; c < p; c++) {
+                const double main_term = var[c + (size_t)p * c] * (double)n;          // sum_w V_c^2 / (nwin len)
+                const double corr = (double)len * hd[c] * hd[c];
+                if (!(corr <= OL_ONEPASS_MAX_LOSS * main_term)) redo = true;           // also catches NaN
+            }
+            if (redo) {
+                rc = launch(dmean.as<double>(), nullptr);
+                if (rc) return rc;
+                HIP_TRY(hipMemcpyAsync(var, dvar.p, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+            }
+        }
         return MCMCHIP_OK;
     }
     const int nt = (p + OL_CT - 1) / OL_CT;

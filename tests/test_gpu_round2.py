@@ -679,6 +679,62 @@ def test_time_sharded_initseq_and_olbm_device_route(api, oracle_mod):
     assert np.max(np.abs(v1 - ref)) <= 1e-10 * np.max(np.abs(ref)) and np.allclose(m1, mean, rtol=1e-13)
 
 
+@pytest.mark.parametrize("n,p,blen", [(1_200_000, 5, 1000), (1_048_576, 70, 64), (1_100_003, 3, 1), (1_300_000, 130, 4097),
+                                       (1_050_000, 2, 525_000), (1_048_581, 2, 1_048_581)])
+def test_olbm_one_pass_route_vs_oracle(api, oracle_mod, n, p, blen):
+    """Series of >= 2^20 rows without supplied means take the one-pass route (diag.hip: window sums about a provisional
+    centre, exact means from the windows that tile the series, rank-two correction of the matrix).  Against the oracle,
+    which computes the means first (olbm.c:38-43), on columns chosen to stress the correction: a large offset, a
+    trend, and a column whose spikes sit exactly on the rows the provisional centre samples (the sample misses the mean
+    by almost the spike height, which has to trigger the repeat about the exact mean)."""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(n % 1000 + p)
+    x = np.empty((n, p))
+    for c in range(p):
+        x[:, c] = lfilter([1.0], [1.0, -(0.2 + 0.7 * c / p)], rng.standard_normal(n)) + (3.0 + 100.0 * (c % 3))
+    if p >= 2:
+        x[:, 1] += np.linspace(-5.0, 5.0, n)                           # trend: the mean is not the mean of any stretch
+    if p >= 3:
+        runs = 4096                                                     # OL_PILOT_RUNS in diag.hip
+        t0 = (np.arange(runs, dtype=np.int64) * (n - 8)) // (runs - 1)
+        x[:, 2] = 1e-3 * rng.standard_normal(n)
+        for k in range(8):
+            x[t0 + k, 2] += 1.0
+    import math
+    ref, refmean = oracle_mod.olbm(x, blen)
+    got = api.olbm(x, blen, demean=False)          # no.calc.mean = FALSE: the device computes the means (R/olbm.R:8-14)
+    # What the reference's arithmetic is good for depends on the shape: olbm.c:38-43 adds the n terms of a mean one after
+    # the other (~sqrt(n) ulp), a window sum moves by len times that error, and olbm.c:52-62 carries one running sum
+    # through all n - len updates.  With len = n/2 that leaves olbm.c itself 1.4e-10 from the true matrix
+    # (tools/olbm_conditioning.py: oracle 1.4e-10, device 6e-14 against an 80-bit evaluation).  So: the device against the
+    # 80-bit evaluation of the definition at 1e-12 (first five columns), and against the oracle at 1e-10, or 1e-8 where
+    # the windows are long.
+    k = min(p, 5)
+    exact = np.array([math.fsum(x[:, c]) / n for c in range(k)])
+    xl = x[:, :k].astype(np.longdouble) - exact.astype(np.longdouble)
+    cs = np.vstack([np.zeros((1, k), dtype=np.longdouble), np.cumsum(xl, axis=0)])
+    V = cs[blen:] - cs[:-blen]
+    true = np.asarray((V.T @ V) / (np.longdouble(n - blen + 1) * n * blen), dtype=np.float64)
+    del xl, cs, V
+    st = np.sqrt(np.outer(np.diag(true), np.diag(true)))
+    assert np.all(np.abs(got[:k, :k] - true) <= 1e-12 * st + 1e-24)
+    scale_ = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    tol = 1e-10 if blen <= 10_000 else 1e-8
+    assert np.all(np.abs(got - ref) <= tol * scale_ + 1e-24)        # len == n: a single window, var is rounding only
+    assert np.array_equal(got, got.T)
+    got2 = api.olbm(x, blen, mean=refmean)         # one kernel, no correction
+    # (a single window about the oracle's sequentially summed mean: the window sum is n times that mean's error, ~5e-6)
+    assert np.all(np.abs(got2 - ref) <= tol * scale_ + 1e-20)
+    # the means the one-pass route returns: centre + delta, good to an ulp of the centre, which for the spike column
+    # (centre ~ 1, mean ~ 0.03) is 4e-15 of the mean
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x.T)).to("cuda:0")
+    v3, m3 = api.olbm_device(xd, blen)
+    assert np.array_equal(v3, got)
+    assert np.allclose(m3[:k], exact, rtol=2e-14, atol=1e-17), (m3[:k] - exact) / exact
+    assert np.allclose(m3, refmean, rtol=1e-11, atol=1e-15)
+
+
 def test_mfma_logdens_bits_do_not_depend_on_the_call_shape(api):
     """ADVICE (round 1): the observation split followed the chain count of the call, so resharding moved log densities
     in the last bits.  The partial sums are now per unit of observations (a function of the data alone): the same state
