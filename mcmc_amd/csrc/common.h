@@ -100,6 +100,9 @@ struct InBuf {
     template <class T> const T *as() const { return (const T *)ptr; }
 };
 
+// hostcopy.hip: device -> pageable host memory; large copies are pipelined through pinned chunks and host threads
+hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipStream_t s);
+
 // an output: the caller's device pointer, or a device staging buffer copied back at the end
 struct OutBuf {
     DevBuf own;
@@ -118,7 +121,7 @@ struct OutBuf {
     }
     hipError_t finish(hipStream_t s)
     {
-        if (host && ptr && bytes) return hipMemcpyAsync(host, ptr, bytes, hipMemcpyDeviceToHost, s);
+        if (host && ptr && bytes) return copy_to_pageable_host(host, ptr, bytes, s);
         return hipSuccess;
     }
     template <class T> T *as() { return (T *)ptr; }

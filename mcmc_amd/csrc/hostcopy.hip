@@ -1,0 +1,111 @@
+// hostcopy.hip -- large results back to the caller's (pageable) host buffers.
+//
+// The reference hands its results to R in freshly allocated R vectors (metrop.c:224-226, temper.c:614-640); through the
+// C-ABI with device_ptrs == 0 that is a device-to-host copy into pageable memory nobody has touched yet.  One
+// hipMemcpy of that kind runs at ~8 GB/s on the box (one runtime thread copies out of its staging buffer and takes
+// every first-touch page fault), which for C2 (1.6 GB of batch means behind a 33 ms kernel) is six sevenths of the
+// call.  Here the copy is pipelined: the DMA engine fills a ring of pinned chunks at PCIe rate while a few host threads
+// move the chunk before it into the destination, page faults included.  No HIP call is made off the calling thread.
+#include "common.h"
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+constexpr size_t HC_CHUNK = (size_t)16 << 20;     // bytes per pinned chunk
+constexpr int HC_NBUF = 4;                        // chunks in the ring
+constexpr size_t HC_MIN_BYTES = (size_t)64 << 20; // smaller copies go straight through hipMemcpyAsync
+
+struct Ring {
+    void *buf[HC_NBUF] = {nullptr, nullptr, nullptr, nullptr};
+    bool tried = false, ok = false;
+};
+std::mutex g_ring_mutex;
+Ring g_ring;                                       // pinned memory is per process, kept until it ends
+
+bool ring_ready()
+{
+    if (g_ring.tried) return g_ring.ok;
+    g_ring.tried = true;
+    for (int i = 0; i < HC_NBUF; i++)
+        if (hipHostMalloc(&g_ring.buf[i], HC_CHUNK, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < i; j++) (void)hipHostFree(g_ring.buf[j]);
+            return false;                          // no pinned memory: the plain copy still works
+        }
+    g_ring.ok = true;
+    return true;
+}
+
+int copy_threads()
+{
+    const char *e = getenv("MCMCHIP_COPY_THREADS");
+    int t = e ? atoi(e) : 8;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && (unsigned)t > hw) t = (int)hw;
+    return t < 1 ? 1 : (t > 32 ? 32 : t);
+}
+}  // namespace
+
+// Everything enqueued on s before the call is complete when it returns (the copies are ordered behind it on s).
+hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipStream_t s)
+{
+    const char *env = getenv("MCMCHIP_COPY_THREADS");                   // "0": the plain copy (for A/B measurements)
+    if (bytes < HC_MIN_BYTES || (env && atoi(env) == 0)) return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    if (!ring_ready()) return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+    hipEvent_t ev[HC_NBUF];
+    for (int i = 0; i < HC_NBUF; i++) {
+        hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; j++) (void)hipEventDestroy(ev[j]);
+            return e;
+        }
+    }
+    const long nchunks = (long)((bytes + HC_CHUNK - 1) / HC_CHUNK);
+    const int T = copy_threads();
+    std::atomic<long> ready{0};                    // chunks [0, ready) have landed in the ring
+    std::atomic<bool> stop{false};
+    std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[nchunks]);
+    for (long c = 0; c < nchunks; c++) done[c].store(0, std::memory_order_relaxed);
+    auto chunk_len = [&](long c) { return c + 1 < nchunks ? HC_CHUNK : bytes - (size_t)c * HC_CHUNK; };
+    auto worker = [&](int t) {
+        for (long c = 0; c < nchunks; c++) {
+            while (ready.load(std::memory_order_acquire) <= c) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            // slices on 4 KiB boundaries: a page of the destination is first touched by one thread
+            const size_t len = chunk_len(c), per = ((len / T + 4095) / 4096) * 4096;
+            const size_t a = (size_t)t * per, b = a + per < len ? a + per : len;
+            if (a < len) memcpy((char *)host + (size_t)c * HC_CHUNK + a, (const char *)g_ring.buf[c % HC_NBUF] + a, b - a);
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(T);
+    for (int t = 0; t < T; t++) pool.emplace_back(worker, t);
+    hipError_t rc = hipSuccess;
+    // the calling thread: issue chunk c, then wait for chunk c - 1 (so one chunk is always queued behind the one in
+    // flight) and hand it to the workers; a ring slot is reused once every worker is done with the chunk it held
+    for (long c = 0; c <= nchunks && rc == hipSuccess; c++) {
+        if (c < nchunks) {
+            if (c >= HC_NBUF)
+                while (done[c - HC_NBUF].load(std::memory_order_acquire) < T) std::this_thread::yield();
+            rc = hipMemcpyAsync(g_ring.buf[c % HC_NBUF], (const char *)dev + (size_t)c * HC_CHUNK, chunk_len(c),
+                                hipMemcpyDeviceToHost, s);
+            if (rc == hipSuccess) rc = hipEventRecord(ev[c % HC_NBUF], s);
+        }
+        if (c >= 1 && rc == hipSuccess) {
+            rc = hipEventSynchronize(ev[(c - 1) % HC_NBUF]);
+            if (rc == hipSuccess) ready.store(c, std::memory_order_release);
+        }
+    }
+    if (rc != hipSuccess) stop.store(true, std::memory_order_relaxed);
+    for (auto &th : pool) th.join();
+    for (int i = 0; i < HC_NBUF; i++) (void)hipEventDestroy(ev[i]);
+    return rc;
+}

@@ -139,6 +139,43 @@ def test_device_pointer_inputs_are_validated(api):
     assert rc == abi.EINVAL and b"all elements of argument must be finite" in L.mcmchip_last_error()
 
 
+def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api, monkeypatch):
+    """Results of 64 MB and more go back to pageable host memory through hostcopy.hip (pinned ring + host threads).
+    The same Philox run with device_ptrs = 1 leaves them in HBM: both must hold the same bits, also when the last chunk
+    is ragged, with one copy thread, and with the plain copy (MCMCHIP_COPY_THREADS = 0)."""
+    import ctypes as C
+    import torch
+    L = api.load_library()
+    dev = torch.device("cuda", 0)
+    X, y = load_logit()
+    tg = api.logistic_target(X, y)
+    Cn, d, nbatch = 4099, 5, 523                      # 85.75 MB of batch means: 5 whole 16 MB chunks and a ragged one
+    rng = np.random.default_rng(3)
+    init_h = 0.1 * rng.standard_normal((Cn, d))
+    scale = np.array([0.4])
+    shapes = ((Cn,), (Cn, nbatch, d), (Cn, d), (Cn, nbatch))
+    init_d = torch.from_numpy(init_h).to(dev)
+    outs_d = [torch.empty(s_, dtype=torch.float64, device=dev) for s_ in shapes]
+    args = abi.MetropArgs(Cn, nbatch, 1, 1, init_d.data_ptr(), abi.SCALE_CONSTANT, scale.ctypes.data, abi.OUT_IDENTITY, None,
+                          abi.RNG_PHILOX, None, None, 7, 0, 0, 0, 1, abi.PATH_STREAM)
+    out = abi.MetropOut(*[t.data_ptr() for t in outs_d], None, None, None, None, None, None, 0, 0, 0)
+    assert L.mcmchip_metrop(tg.handle, C.addressof(args), C.addressof(out)) == 0, L.mcmchip_last_error()
+    want = [t.cpu().numpy() for t in outs_d]
+    assert want[1].nbytes >= 64 << 20
+    for threads in (None, "1", "0"):
+        if threads is None:
+            monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("MCMCHIP_COPY_THREADS", threads)
+        outs_h = [np.full(s_, np.nan) for s_ in shapes]
+        args_h = abi.MetropArgs(Cn, nbatch, 1, 1, init_h.ctypes.data, abi.SCALE_CONSTANT, scale.ctypes.data, abi.OUT_IDENTITY,
+                                None, abi.RNG_PHILOX, None, None, 7, 0, 0, 0, 0, abi.PATH_STREAM)
+        out_h = abi.MetropOut(*[a_.ctypes.data for a_ in outs_h], None, None, None, None, None, None, 0, 0, 0)
+        assert L.mcmchip_metrop(tg.handle, C.addressof(args_h), C.addressof(out_h)) == 0, L.mcmchip_last_error()
+        for got, ref in zip(outs_h, want):
+            assert np.array_equal(got, ref), threads
+
+
 # ----------------------------------------------------------------------------- the configuration bench.py times (C3)
 def _synthetic(n, d, seed=42):
     rng = np.random.default_rng(seed)
