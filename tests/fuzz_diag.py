@@ -13,7 +13,7 @@ from mcmc_amd import api  # noqa: E402
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
-    n = int(rng.choice([2, 3, 5, 63, 64, 65, 127, 129, 1000, 2047, 2048, 2049, 4097, 30000, 65520, 65536, 65553, 131100]))
+    n = int(rng.choice([2, 3, 5, 63, 64, 65, 127, 129, 1000, 2047, 2048, 2049, 4097, 30000, 65520, 65536, 65553, 131100, 1_048_576, 1_200_001]))
     p = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 64, 65, 100, 129, 255, 256, 257]))
     if n * p > 6_000_000:
         p = max(1, 6_000_000 // n)
@@ -29,6 +29,11 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     ref, _ = oracle.olbm(x, blen)
     got = api.olbm(x, blen)
     err_o = np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) + 1e-18)      # len == n: the reference is exactly 0
+    # no.calc.mean = FALSE: the device computes the means (n >= 2^20: the one-pass route of diag.hip, whose means are
+    # closer to the truth than olbm.c's sequential sums -- with long windows that alone moves the matrix by ~1e-10)
+    got_d = api.olbm(x, blen, demean=False)
+    err_d = np.max(np.abs(got_d - ref)) / (np.max(np.abs(ref)) + 1e-18)
+    err_o = max(err_o, err_d / (5.0 if n >= (1 << 20) else 1.0))
     # initseq on a few columns
     cols = rng.choice(p, size=min(p, 5), replace=False)
     res = api.initseq(x[:, cols])
