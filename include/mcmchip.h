@@ -312,7 +312,9 @@ int mcmchip_initseq_from_lagsums(const double *sums, int64_t len, int64_t ncol, 
 
 /* olbm -- replaces void olbm(double *x, int *nin, int *pin, int *lin, double *mean,
  * double *var, int *nocalcin) (mcmc.h:16-17, olbm.c:22-78).  x is n x p column-major.
- * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned. */
+ * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned (for n >= 2^20 and p <= 256
+ * in the same pass over x as the matrix, not in a pass of their own as in olbm.c:38-43; they come out correctly
+ * rounded to an ulp, where the reference's sequential sum is good to ~sqrt(n) ulp). */
 int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
                  int32_t nocalc, int device_ptrs);
 
