@@ -1294,7 +1294,9 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
             for (int c = 0; c < p; c++) {
                 const double main_term = var[c + (size_t)p * c] * (double)n;          // sum_w V_c^2 / (nwin len)
                 const double corr = (double)len * hd[c] * hd[c];
-                if (!(corr <= OL_ONEPASS_MAX_LOSS * main_term)) redo = true;           // also catches NaN
+                // (a delta that is rounding of the centre itself, as for a constant column, cancels nothing)
+                if (!(corr <= OL_ONEPASS_MAX_LOSS * main_term) && !(fabs(hd[c]) <= 1e-14 * fabs(mean[c])))
+                    redo = true;                                                        // also catches NaN
             }
             if (redo) {
                 rc = launch(dmean.as<double>(), nullptr);

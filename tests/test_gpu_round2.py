@@ -731,6 +731,8 @@ def test_olbm_one_pass_route_vs_oracle(api, oracle_mod, n, p, blen):
         x[:, c] = lfilter([1.0], [1.0, -(0.2 + 0.7 * c / p)], rng.standard_normal(n)) + (3.0 + 100.0 * (c % 3))
     if p >= 2:
         x[:, 1] += np.linspace(-5.0, 5.0, n)                           # trend: the mean is not the mean of any stretch
+    if p >= 5:
+        x[:, 4] = 7.25                                                  # a constant column: variance exactly 0
     if p >= 3:
         runs = 4096                                                     # OL_PILOT_RUNS in diag.hip
         t0 = (np.arange(runs, dtype=np.int64) * (n - 8)) // (runs - 1)
