@@ -310,6 +310,15 @@ int mcmchip_initseq_from_lagsums(const double *sums, int64_t len, int64_t ncol, 
                                  double *gamma0, double *Gamma_pos, double *Gamma_dec, double *Gamma_con,
                                  double *var_pos, double *var_dec, double *var_con);
 
+/* A series kept in HBM between calls -- no counterpart in the reference, where the batch matrix lives in R's heap.
+ * Uploads the n x p host matrix x once and returns a device pointer laid out as initseq / lagsums / olbm want it
+ * (column-major, x[t + n*c], the reference's X(I,J) of olbm.c:19) for use with device_ptrs = 1: initseq and olbm on the
+ * same batch then cross PCIe once instead of twice.  row_major != 0: x is in C order (x[t*p + c], what numpy and most
+ * non-R callers hold); it is uploaded as it is and transposed on the device, which is ~10x faster than transposing a
+ * large matrix on the host first.  The pointer is released with mcmchip_series_free (NULL is allowed). */
+int mcmchip_series_upload(const double *x, int64_t n, int64_t p, int row_major, double **dev);
+int mcmchip_series_free(double *dev);
+
 /* olbm -- replaces void olbm(double *x, int *nin, int *pin, int *lin, double *mean,
  * double *var, int *nocalcin) (mcmc.h:16-17, olbm.c:22-78).  x is n x p column-major.
  * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned (for n >= 2^20 and p <= 256

@@ -148,6 +148,8 @@ EXPORTS = [
     "mcmchip_lagsums",
     "mcmchip_initseq_from_lagsums",
     "mcmchip_olbm",
+    "mcmchip_series_upload",
+    "mcmchip_series_free",
     "mcmchip_set_interrupt_poll",
     "mcmchip_set_launch_limit",
     "mcmchip_last_kernel_time",

@@ -67,6 +67,10 @@ def load_library():
     L.mcmchip_olbm.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_int]
     L.mcmchip_olbm.restype = C.c_int
+    L.mcmchip_series_upload.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+    L.mcmchip_series_upload.restype = C.c_int
+    L.mcmchip_series_free.argtypes = [C.c_void_p]
+    L.mcmchip_series_free.restype = C.c_int
     L.mcmchip_last_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
     L.mcmchip_last_kernel_time.restype = C.c_int
     L.mcmchip_sync.restype = C.c_int
@@ -450,28 +454,36 @@ def tune_pseudo_prior(x, y, models, initial, neighbors, nbatch, blen=1, nspac=1,
             "rounds": rounds, "out": out}
 
 
-def initseq(x):
+def initseq(x, centred=False):
     """initseq(x): R/initseq.R:1-5 -- x numeric, all finite; the series is centred here and the
     centred series goes to the native routine.  A 2-d x (len x ncol) is a batch of series and
-    returns a list of results."""
-    x = np.asarray(x)
-    if not np.issubdtype(x.dtype, np.number):
-        raise TypeError("is.numeric(x) is not TRUE")
-    x = x.astype(np.float64)
-    if not np.all(np.isfinite(x)):
-        raise ValueError("all(is.finite(x)) is not TRUE")
-    single = x.ndim == 1
-    xm = x[:, None] if single else x
-    length, ncol = xm.shape
-    xc = np.ascontiguousarray((xm - xm.mean(axis=0)).T)      # column-major len x ncol
+    returns a list of results.
+    A DeviceSeries (upload_series) is taken as the native routine takes its argument (initseq.c:7): centred already,
+    which the caller states with centred = True; the device checks that it is finite."""
+    if isinstance(x, DeviceSeries):
+        if not centred:
+            raise ValueError("a DeviceSeries goes to the native routine as it is: centre it first and pass centred=True")
+        single = False
+        src = x
+    else:
+        x = np.asarray(x)
+        if not np.issubdtype(x.dtype, np.number):
+            raise TypeError("is.numeric(x) is not TRUE")
+        x = x.astype(np.float64)
+        if not np.all(np.isfinite(x)):
+            raise ValueError("all(is.finite(x)) is not TRUE")
+        single = x.ndim == 1
+        xm = x[:, None] if single else x
+        src = xm if centred else xm - xm.mean(axis=0)
     init()
+    ptr, length, ncol, dp, keep = _colmajor(src)             # column-major len x ncol, on the host or in HBM
     L = load_library()
     cap = max(min(length // 2, 4096), 1)
     while True:
         n_out = np.zeros(ncol, dtype=np.int64)
         g0, vp, vd, vc = (np.empty(ncol) for _ in range(4))
         Gp, Gd, Gc = (np.empty((ncol, cap)) for _ in range(3))
-        rc = L.mcmchip_initseq(xc.ctypes.data, length, ncol, 0, cap, n_out.ctypes.data, g0.ctypes.data,
+        rc = L.mcmchip_initseq(ptr, length, ncol, dp, cap, n_out.ctypes.data, g0.ctypes.data,
                                Gp.ctypes.data, Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data,
                                vd.ctypes.data, vc.ctypes.data)
         if rc == abi.ECAP:
@@ -487,10 +499,53 @@ def initseq(x):
     return res[0] if single else res
 
 
+class DeviceSeries:
+    """A len x ncol batch of series resident in HBM in the diagnostics' column-major layout (mcmchip_series_upload):
+    pass it to initseq / lagsums / olbm / olbm_device in place of the array, as often as needed; PCIe is crossed once."""
+
+    def __init__(self, ptr, length, ncol):
+        self.ptr, self.length, self.ncol = ptr, int(length), int(ncol)
+
+    def free(self):
+        if self.ptr:
+            ptr, self.ptr = self.ptr, None
+            try:
+                load_library().mcmchip_series_free(ptr)
+            except Exception:           # interpreter shutdown: the library may be gone already
+                pass
+
+    __del__ = free
+
+
+# host arrays at least this large that are not already column-major go to the device as they are and are transposed
+# there (numpy transposes a 1 GB matrix at ~0.4-2.5 GB/s; the upload runs at ~25 GB/s and the device transpose at TB/s)
+_UPLOAD_MIN_BYTES = 8 << 20
+
+
+def upload_series(x):
+    """numpy len x ncol (or a vector) -> DeviceSeries.  A Fortran-ordered array (R's layout) is uploaded as it is, a
+    C-ordered one is uploaded as it is and transposed on the device."""
+    init()
+    a = np.asarray(x, dtype=np.float64)
+    if a.ndim == 1:
+        a = a[:, None]
+    length, ncol = a.shape
+    if a.flags.f_contiguous:
+        src, row_major = a, 0
+    else:
+        src, row_major = np.ascontiguousarray(a), 1
+    out = C.c_void_p()
+    _check(load_library().mcmchip_series_upload(src.ctypes.data, length, ncol, row_major, C.byref(out)))
+    return DeviceSeries(out.value, length, ncol)
+
+
 def _colmajor(x):
     """(pointer, len, ncol, device_ptrs, keepalive) of a batch of series for the C-ABI's column-major layout x[t + len*c].
-    numpy: len x ncol (or a vector), copied into column-major order.  torch CUDA tensor: ncol x len contiguous (already
-    column-major from R's point of view), used in place -- nothing crosses PCIe."""
+    numpy: len x ncol (or a vector); column-major (Fortran-ordered) arrays are used in place, small C-ordered ones are
+    transposed on the host, large ones on the device (upload_series).  DeviceSeries and torch CUDA tensors (ncol x len
+    contiguous: already column-major from R's point of view) are used in place -- nothing crosses PCIe."""
+    if isinstance(x, DeviceSeries):
+        return x.ptr, x.length, x.ncol, 1, x
     if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
         if not x.is_cuda or x.dim() != 2 or not x.is_contiguous() or str(x.dtype) != "torch.float64":
             raise ValueError("device series must be a contiguous float64 CUDA tensor of shape (ncol, len)")
@@ -498,6 +553,9 @@ def _colmajor(x):
     a = np.asarray(x, dtype=np.float64)
     if a.ndim == 1:
         a = a[:, None]
+    if a.nbytes >= _UPLOAD_MIN_BYTES and a.shape[1] > 1 and not a.flags.f_contiguous:
+        ds = upload_series(a)
+        return ds.ptr, ds.length, ds.ncol, 1, ds
     xc = np.ascontiguousarray(a.T)
     return xc.ctypes.data, a.shape[0], a.shape[1], 0, xc
 
@@ -554,14 +612,18 @@ def olbm(x, batch_length, demean=True, mean=None):
     native routine recomputes the means (R/olbm.R:8-14 with olbm.c:37): both settings demean.
     mean (not an argument of the R front end): the native routine's no.calc.mean = TRUE contract with means
     supplied by the caller (olbm.c:37-43), used by the time-sharded driver mcmc_amd.dist.olbm_sharded."""
-    x = np.asarray(x, dtype=np.float64)
-    if x.ndim == 1:
-        x = x[:, None]
-    n, p = x.shape
+    if isinstance(x, DeviceSeries):
+        if mean is None and demean:
+            demean = False              # the means of a resident series are the device's to compute (same result)
+        n, p = x.length, x.ncol
+    else:
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[:, None]
+        n, p = x.shape
     batch_length = int(batch_length)
     if batch_length > n:
         raise ValueError("batch.length must be <= nrow(x)")
-    xc = np.ascontiguousarray(x.T)                           # column-major n x p
     if mean is not None:
         mean = np.asarray(mean, dtype=np.float64).copy()
         if mean.shape != (p,):
@@ -576,6 +638,7 @@ def olbm(x, batch_length, demean=True, mean=None):
     mean = np.ascontiguousarray(mean, dtype=np.float64)
     var = np.empty((p, p))
     init()
-    _check(load_library().mcmchip_olbm(xc.ctypes.data, n, p, batch_length, mean.ctypes.data,
-                                       var.ctypes.data, int(no_calc_mean), 0))
+    ptr, n, p, dp, keep = _colmajor(x)                      # column-major n x p, on the host or in HBM
+    _check(load_library().mcmchip_olbm(ptr, n, p, batch_length, mean.ctypes.data,
+                                       var.ctypes.data, int(no_calc_mean), dp))
     return var

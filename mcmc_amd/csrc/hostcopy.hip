@@ -1,4 +1,4 @@
-// hostcopy.hip -- large results back to the caller's (pageable) host buffers.
+// hostcopy.hip -- large results back to the caller's (pageable) host buffers, and a host series into HBM.
 //
 // The reference hands its results to R in freshly allocated R vectors (metrop.c:224-226, temper.c:614-640); through the
 // C-ABI with device_ptrs == 0 that is a device-to-host copy into pageable memory nobody has touched yet.  One
@@ -108,4 +108,55 @@ hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipS
     for (auto &th : pool) th.join();
     for (int i = 0; i < HC_NBUF; i++) (void)hipEventDestroy(ev[i]);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mcmchip_series_upload / mcmchip_series_free (include/mcmchip.h): a host matrix into HBM in the column-major layout the
+// diagnostics read, transposed on the device when the host holds it in C order.
+// 64 x 64 tiles through LDS: rows of the input are read along p (contiguous), columns of the output written along n.
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const double *__restrict__ in, long n, long p,
+                                                             double *__restrict__ out)
+{
+    __shared__ double tile[64][65];
+    const long r0 = (long)blockIdx.x * 64, c0 = (long)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < n && c0 + tx < p) tile[i][tx] = in[(size_t)(r0 + i) * p + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4)
+        if (c0 + j < p && r0 + tx < n) out[(size_t)(c0 + j) * n + r0 + tx] = tile[tx][j];
+}
+
+extern "C" int mcmchip_series_upload(const double *x, int64_t n, int64_t p, int row_major, double **dev)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!x || !dev || n <= 0 || p <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_series_upload");
+    if ((n + 63) / 64 > 0x7fffffffL || (p + 63) / 64 > 65535) return set_error(MCMCHIP_EINVAL, "series too large to tile");
+    *dev = nullptr;
+    const size_t bytes = (size_t)n * (size_t)p * 8;
+    DevBuf out, raw;
+    HIP_TRY(out.alloc(bytes));
+    hipStream_t s = dc->stream;
+    if (!row_major || p == 1) {
+        HIP_TRY(hipMemcpyAsync(out.p, x, bytes, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(raw.alloc(bytes));
+        HIP_TRY(hipMemcpyAsync(raw.p, x, bytes, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(transpose_rows_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((p + 63) / 64)), dim3(256), 0, s,
+                           raw.as<double>(), (long)n, (long)p, out.as<double>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));            // raw is released on return
+    *dev = out.as<double>();
+    out.p = nullptr;                             // ownership passes to the caller
+    return MCMCHIP_OK;
+}
+
+extern "C" int mcmchip_series_free(double *dev)
+{
+    clear_error();
+    if (dev) HIP_TRY(hipFree(dev));
+    return MCMCHIP_OK;
 }

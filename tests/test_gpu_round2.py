@@ -176,6 +176,57 @@ def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api
             assert np.array_equal(got, ref), threads
 
 
+def test_series_upload_and_device_transpose(api, oracle_mod):
+    """mcmchip_series_upload: a host matrix into HBM once, in the diagnostics' column-major layout, transposed on the
+    device when the host holds it in C order (ragged 64 x 64 tiles included).  initseq / lagsums / olbm on the resident
+    series give the bits of the host-pointer calls, and large C-ordered numpy arrays take that route by themselves."""
+    import ctypes as C
+    from scipy.signal import lfilter
+    L = api.load_library()
+    assert L.mcmchip_series_free(None) == 0
+    rng = np.random.default_rng(21)
+    for n, p in ((1000, 3), (4097, 65), (70, 130), (200_003, 9)):
+        x = lfilter([1.0], [1.0, -0.6], rng.standard_normal((n, p)), axis=0) + rng.uniform(-2, 2, p)
+        xc = x - x.mean(axis=0)
+        blen = max(1, n // 40)
+        mu = x.mean(axis=0)         # one set of means for every route (numpy sums C and Fortran order differently)
+        host = api.olbm(np.asfortranarray(x), blen, mean=mu)    # column-major host array: used in place, no upload
+        for arr in (x, np.asfortranarray(x)):                   # C order (device transpose) and Fortran order
+            ds = api.upload_series(arr)
+            assert (ds.length, ds.ncol) == (n, p)
+            assert np.array_equal(api.olbm(ds, blen, mean=mu), host)
+            v, m = api.olbm_device(ds, blen)
+            ref, refmean = oracle_mod.olbm(x, blen)
+            assert np.max(np.abs(v - ref)) <= 1e-10 * np.max(np.abs(ref)) and np.allclose(m, refmean, rtol=1e-12)
+            ds.free()
+            ds.free()                                           # idempotent
+        ds = api.upload_series(xc)
+        a, b = api.lagsums(ds, 16), api.lagsums(np.asfortranarray(xc), 16)
+        assert np.array_equal(a, b)
+        ra, rb = api.initseq(ds, centred=True), api.initseq(np.asfortranarray(xc), centred=True)
+        for ca, cb in zip(ra, rb):
+            for key in ca:
+                assert np.array_equal(ca[key], cb[key])
+        with pytest.raises(ValueError, match="centred=True"):
+            api.initseq(ds)
+    # a C-ordered array above the threshold goes through the upload by itself: same bits as the in-place column-major call
+    n, p = 300_000, 7
+    x = rng.standard_normal((n, p)).cumsum(axis=0) * 1e-3 + rng.standard_normal((n, p))
+    assert x.nbytes >= api._UPLOAD_MIN_BYTES and not x.flags.f_contiguous
+    mu = x.mean(axis=0)
+    assert np.array_equal(api.olbm(x, 500, mean=mu), api.olbm(np.asfortranarray(x), 500, mean=mu))
+    assert np.max(np.abs(api.olbm(x, 500) - api.olbm(x, 500, mean=mu))) == 0.0       # demean = TRUE computes those means
+    xc = x - mu
+    r1, r2 = api.initseq(xc, centred=True), api.initseq(np.asfortranarray(xc), centred=True)
+    for ca, cb in zip(r1, r2):
+        for key in ca:
+            assert np.array_equal(ca[key], cb[key])
+    # bad arguments
+    out = C.c_void_p()
+    assert L.mcmchip_series_upload(None, 10, 2, 0, C.byref(out)) == abi.EINVAL
+    assert L.mcmchip_series_upload(x.ctypes.data, 0, 2, 0, C.byref(out)) == abi.EINVAL
+
+
 # ----------------------------------------------------------------------------- the configuration bench.py times (C3)
 def _synthetic(n, d, seed=42):
     rng = np.random.default_rng(seed)
