@@ -318,6 +318,9 @@ int mcmchip_initseq_from_lagsums(const double *sums, int64_t len, int64_t ncol, 
  * large matrix on the host first.  The pointer is released with mcmchip_series_free (NULL is allowed). */
 int mcmchip_series_upload(const double *x, int64_t n, int64_t p, int row_major, double **dev);
 int mcmchip_series_free(double *dev);
+/* x - mean(x) per column, in place on a resident series (R/initseq.R:3 does it in R before the native call); the
+ * means go to `mean` (host, p doubles) when it is not NULL.  No counterpart in the reference's C. */
+int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean);
 
 /* olbm -- replaces void olbm(double *x, int *nin, int *pin, int *lin, double *mean,
  * double *var, int *nocalcin) (mcmc.h:16-17, olbm.c:22-78).  x is n x p column-major.

@@ -150,6 +150,7 @@ EXPORTS = [
     "mcmchip_olbm",
     "mcmchip_series_upload",
     "mcmchip_series_free",
+    "mcmchip_series_centre",
     "mcmchip_set_interrupt_poll",
     "mcmchip_set_launch_limit",
     "mcmchip_last_kernel_time",

@@ -71,6 +71,8 @@ def load_library():
     L.mcmchip_series_upload.restype = C.c_int
     L.mcmchip_series_free.argtypes = [C.c_void_p]
     L.mcmchip_series_free.restype = C.c_int
+    L.mcmchip_series_centre.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    L.mcmchip_series_centre.restype = C.c_int
     L.mcmchip_last_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
     L.mcmchip_last_kernel_time.restype = C.c_int
     L.mcmchip_sync.restype = C.c_int
@@ -469,12 +471,20 @@ def initseq(x, centred=False):
         x = np.asarray(x)
         if not np.issubdtype(x.dtype, np.number):
             raise TypeError("is.numeric(x) is not TRUE")
-        x = x.astype(np.float64)
-        if not np.all(np.isfinite(x)):
-            raise ValueError("all(is.finite(x)) is not TRUE")
+        x = np.asarray(x, dtype=np.float64)
         single = x.ndim == 1
         xm = x[:, None] if single else x
-        src = xm if centred else xm - xm.mean(axis=0)
+        if x.nbytes >= _UPLOAD_MIN_BYTES:
+            # a large series: uploaded as it is, centred (and checked for non-finite values) on the device -- three
+            # passes over a GB-sized array on the host cost ten times the upload
+            init()
+            src = upload_series(xm)
+            if not centred:
+                src.centre()
+        else:
+            if not np.all(np.isfinite(x)):
+                raise ValueError("all(is.finite(x)) is not TRUE")
+            src = xm if centred else xm - xm.mean(axis=0)
     init()
     ptr, length, ncol, dp, keep = _colmajor(src)             # column-major len x ncol, on the host or in HBM
     L = load_library()
@@ -489,6 +499,8 @@ def initseq(x, centred=False):
         if rc == abi.ECAP:
             cap = int(n_out.max())
             continue
+        if rc == abi.EINVAL and b"must be finite" in L.mcmchip_last_error():
+            raise ValueError("all(is.finite(x)) is not TRUE")
         _check(rc)
         break
     res = []
@@ -505,6 +517,12 @@ class DeviceSeries:
 
     def __init__(self, ptr, length, ncol):
         self.ptr, self.length, self.ncol = ptr, int(length), int(ncol)
+
+    def centre(self):
+        """subtract the column means in place (R/initseq.R:3, on the device); returns the means"""
+        mean = np.empty(self.ncol)
+        _check(load_library().mcmchip_series_centre(self.ptr, self.length, self.ncol, mean.ctypes.data))
+        return mean
 
     def free(self):
         if self.ptr:

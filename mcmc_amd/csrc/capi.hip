@@ -745,6 +745,15 @@ int mcmchip_lagsums(const double *x, int64_t len, int64_t ncol, int64_t nlags, i
     return run_lagsums(in.as<double>(), len, ncol, nlags, sums, dc);
 }
 
+int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!dev || n <= 0 || p <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_series_centre");
+    return run_series_centre(dev, n, p, mean, dc);
+}
+
 int mcmchip_initseq_from_lagsums(const double *sums, int64_t len, int64_t ncol, int64_t nlags, int64_t cap, int64_t *n_out,
                                  double *gamma0, double *Gamma_pos, double *Gamma_dec, double *Gamma_con,
                                  double *var_pos, double *var_dec, double *var_con)

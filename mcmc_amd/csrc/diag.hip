@@ -647,6 +647,37 @@ __global__ void colmean_kernel(const double *__restrict__ partial, long nchunk, 
 }
 
 // one workgroup = one time segment x one 64 x 64 tile pair (ti >= tj) of var.
+// x - mean(x) per column in place (mcmchip_series_centre): what R/initseq.R:3 does in R before the native call
+__global__ __launch_bounds__(256) void centre_kernel(double *__restrict__ x, long n, const double *__restrict__ mean)
+{
+    double *xc = x + (size_t)blockIdx.y * n;
+    const double m = mean[blockIdx.y];
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) xc[t] -= m;
+}
+
+int run_series_centre(double *x, long n, long p, double *mean, DeviceCtx *dc)
+{
+    hipStream_t s = dc->stream;
+    if (p > 65535) return set_error(MCMCHIP_EINVAL, "too many columns");
+    const long chunk = 1 << 20, nchunk = (n + chunk - 1) / chunk;
+    DevBuf cpart, dmean;
+    HIP_TRY(cpart.alloc((size_t)p * nchunk * 8));
+    HIP_TRY(dmean.alloc((size_t)p * 8));
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nchunk, (unsigned)p), dim3(256), 0, s, x, n, chunk, nchunk,
+                       cpart.as<double>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((p + 63) / 64)), dim3(64), 0, s, cpart.as<double>(), nchunk, n, (int)p,
+                       dmean.as<double>());
+    HIP_TRY(hipGetLastError());
+    long gx = (n + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(centre_kernel, dim3((unsigned)gx, (unsigned)p), dim3(256), 0, s, x, n, dmean.as<double>());
+    HIP_TRY(hipGetLastError());
+    if (mean) HIP_TRY(hipMemcpyAsync(mean, dmean.p, (size_t)p * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return MCMCHIP_OK;
+}
+
 // Phase 1 (per 64-window slab): each wave rebuilds the centred window sums of 32 of the 128 columns with a
 //   wave prefix scan over x[t+len] - x[t] (lanes = consecutive windows: coalesced 512-B loads) -> LDS.
 // Phase 2: every thread holds a 4 x 4 block of the 64 x 64 output in registers and walks the 64 windows

@@ -100,5 +100,6 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
 int run_lagsums(const double *x, long len, long ncol, long nlags, double *sums, DeviceCtx *dc);
 int run_initseq_from_lagsums(const double *sums, long len, long ncol, long nlags, long cap, long *n_out, double *gamma0,
                              double *Gpos, double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon);
+int run_series_centre(double *x, long n, long p, double *mean, DeviceCtx *dc);
 int run_olbm(const double *x, long n, int p, long len, double *mean, double *var, int nocalc,
              DeviceCtx *dc);

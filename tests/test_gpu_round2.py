@@ -221,8 +221,32 @@ def test_series_upload_and_device_transpose(api, oracle_mod):
     for ca, cb in zip(r1, r2):
         for key in ca:
             assert np.array_equal(ca[key], cb[key])
+    # initseq on a large array: uploaded raw, centred and checked on the device (mcmchip_series_centre).  AR(1) columns:
+    # the stopping lag stays in the hundreds, so the CPU oracle finishes in seconds
+    y = np.column_stack([lfilter([1.0], [1.0, -rho], rng.standard_normal(n)) for rho in np.linspace(0.1, 0.9, p)]) + 3.0
+    assert y.nbytes >= api._UPLOAD_MIN_BYTES and not y.flags.f_contiguous
+    r3 = api.initseq(y)
+    for c in range(p):
+        ref = oracle_mod.initseq(y[:, c] - y[:, c].mean())
+        assert len(r3[c]["Gamma.pos"]) == len(ref["Gamma.pos"])
+        for key in ("gamma0", "Gamma.pos", "Gamma.dec", "Gamma.con", "var.pos", "var.dec", "var.con"):
+            assert np.max(np.abs(np.asarray(r3[c][key]) - np.asarray(ref[key]))) <= 1e-10 * np.max(np.abs(ref[key])), (c, key)
+    ds = api.upload_series(y)
+    got_mu = ds.centre()
+    assert np.allclose(got_mu, y.mean(axis=0), rtol=1e-13, atol=1e-15)
+    assert np.allclose(ds.centre(), 0.0, atol=1e-15)             # centred now
+    ds.free()
+    ybad = y.copy()
+    ybad[123_456, 3] = np.inf
+    with pytest.raises(ValueError, match="is.finite"):
+        api.initseq(ybad)
+    v = lfilter([1.0], [1.0, -0.7], rng.standard_normal(1_100_000)) + 5.0      # one long series (8.8 MB)
+    rv, ref = api.initseq(v), oracle_mod.initseq(v - v.mean())
+    assert len(rv["Gamma.pos"]) == len(ref["Gamma.pos"])
+    assert abs(rv["var.con"] - ref["var.con"]) <= 1e-10 * abs(ref["var.con"])
     # bad arguments
     out = C.c_void_p()
+    assert L.mcmchip_series_centre(None, 10, 2, None) == abi.EINVAL
     assert L.mcmchip_series_upload(None, 10, 2, 0, C.byref(out)) == abi.EINVAL
     assert L.mcmchip_series_upload(x.ctypes.data, 0, 2, 0, C.byref(out)) == abi.EINVAL
 
