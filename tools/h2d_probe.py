@@ -31,3 +31,15 @@ for n, p in ((4_000_000, 32), (2_000_000, 256)):
         t1 = time.perf_counter()
         print("   api.olbm(C-ordered numpy) %.1f ms" % ((t1 - t0) * 1e3), flush=True)
     assert np.array_equal(v, var)
+    if p == 32:
+        # initseq through the mirror: raw upload, centring and the finite check on the device; against the host steps
+        # it replaces (finite check, mean, subtraction, transpose), timed here with numpy on the same array
+        for rep in range(2):
+            t0 = time.perf_counter()
+            r = api.initseq(x)
+            t1 = time.perf_counter()
+            print("   api.initseq(C-ordered numpy) %.1f ms" % ((t1 - t0) * 1e3), flush=True)
+        t0 = time.perf_counter()
+        ok = np.all(np.isfinite(x)); xcen = x - x.mean(axis=0); xt = np.ascontiguousarray(xcen.T)
+        t1 = time.perf_counter()
+        print("   the host steps it replaces: %.1f ms" % ((t1 - t0) * 1e3), flush=True)
