@@ -1012,11 +1012,17 @@ __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__r
         base = runc + excl;
         double *rowp = Vdst + (ph * WPP) * LD + pcol;
         if (r0 + OM_SLAB <= nwl) {
+            // (one uniform branch around the loop: left inside it, the compiler tests wave_dups once per window)
+            if (wave_dups) {
 #pragma unroll
-            for (int k = 0; k < WPP; k++) {
-                const double v = k == 0 ? base : base + dv[k - 1];
-                rowp[k * LD] = v;
-                if (wave_dups) rowp[k * LD + dupoff] = v;
+                for (int k = 0; k < WPP; k++) {
+                    const double v = k == 0 ? base : base + dv[k - 1];
+                    rowp[k * LD] = v;
+                    rowp[k * LD + dupoff] = v;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < WPP; k++) rowp[k * LD] = k == 0 ? base : base + dv[k - 1];
             }
         } else {                                                       // the segment's last slab (or past it)
             const int left = nwl - (r0 + ph * WPP);
