@@ -243,7 +243,9 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             t->n = desc->n;
             size_t xb = (size_t)desc->n * desc->d * 8, yb = (size_t)desc->n * 8;
             if (hipMalloc((void **)&t->x, xb) != hipSuccess || hipMalloc((void **)&t->y, yb) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "hipMalloc of the design matrix failed"); break; }
-            if (hipMemcpyAsync(t->x, desc->x, xb, kind, dc->stream) != hipSuccess ||
+            // (a host design matrix of 64 MB and more goes up through the pinned ring of hostcopy.hip)
+            if ((desc_device_ptrs ? hipMemcpyAsync(t->x, desc->x, xb, kind, dc->stream)
+                                  : copy_from_pageable_host(t->x, desc->x, xb, dc->stream)) != hipSuccess ||
                 hipMemcpyAsync(t->y, desc->y, yb, kind, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of the design matrix failed"); break; }
             if (desc->kind == MCMCHIP_T_LOGISTIC && desc->d <= MCMCHIP_MFMA_MAXD) {
                 rc = build_mfma_tiles(t, dc->stream);

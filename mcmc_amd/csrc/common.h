@@ -84,6 +84,10 @@ struct DevBuf {
     template <class T> T *as() { return (T *)p; }
 };
 
+// hostcopy.hip: pageable host memory <-> HBM; large copies are pipelined through pinned chunks and host threads
+hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipStream_t s);
+hipError_t copy_from_pageable_host(void *dev, const void *host, size_t bytes, hipStream_t s);
+
 // bring an input into HBM: either the caller's device pointer as-is, or a staged copy
 struct InBuf {
     DevBuf own;
@@ -95,13 +99,10 @@ struct InBuf {
         hipError_t e = own.alloc(bytes);
         if (e != hipSuccess) return e;
         ptr = own.p;
-        return hipMemcpyAsync(own.p, src, bytes, hipMemcpyHostToDevice, s);
+        return copy_from_pageable_host(own.p, src, bytes, s);
     }
     template <class T> const T *as() const { return (const T *)ptr; }
 };
-
-// hostcopy.hip: device -> pageable host memory; large copies are pipelined through pinned chunks and host threads
-hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipStream_t s);
 
 // an output: the caller's device pointer, or a device staging buffer copied back at the end
 struct OutBuf {

@@ -110,6 +110,69 @@ hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipS
     return rc;
 }
 
+// The other direction: pageable host memory into HBM.  One hipMemcpy runs at ~27 GB/s on the box (the runtime stages
+// through its own pinned buffer on one thread); here host threads fill the pinned ring while the DMA engine empties the
+// chunk before.  The source must stay valid until the call returns; on return the copies are enqueued AND complete.
+hipError_t copy_from_pageable_host(void *dev, const void *host, size_t bytes, hipStream_t s)
+{
+    const char *env = getenv("MCMCHIP_COPY_THREADS");
+    if (bytes < HC_MIN_BYTES || (env && atoi(env) == 0)) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    if (!ring_ready()) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
+    hipEvent_t ev[HC_NBUF];
+    for (int i = 0; i < HC_NBUF; i++) {
+        hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; j++) (void)hipEventDestroy(ev[j]);
+            return e;
+        }
+    }
+    const long nchunks = (long)((bytes + HC_CHUNK - 1) / HC_CHUNK);
+    const int T = copy_threads();
+    std::atomic<long> freed{0};                    // chunks [0, freed) have left the ring: slot c % HC_NBUF may take chunk c when c < freed + HC_NBUF
+    std::atomic<bool> stop{false};
+    std::unique_ptr<std::atomic<int>[]> filled(new std::atomic<int>[nchunks]);
+    for (long c = 0; c < nchunks; c++) filled[c].store(0, std::memory_order_relaxed);
+    auto chunk_len = [&](long c) { return c + 1 < nchunks ? HC_CHUNK : bytes - (size_t)c * HC_CHUNK; };
+    auto worker = [&](int t) {
+        for (long c = 0; c < nchunks; c++) {
+            while (freed.load(std::memory_order_acquire) + HC_NBUF <= c) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const size_t len = chunk_len(c), per = ((len / T + 4095) / 4096) * 4096;
+            const size_t a = (size_t)t * per, b = a + per < len ? a + per : len;
+            if (a < len) memcpy((char *)g_ring.buf[c % HC_NBUF] + a, (const char *)host + (size_t)c * HC_CHUNK + a, b - a);
+            filled[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(T);
+    for (int t = 0; t < T; t++) pool.emplace_back(worker, t);
+    hipError_t rc = hipSuccess;
+    long retired = 0;                              // chunks whose DMA is known complete
+    for (long c = 0; c < nchunks && rc == hipSuccess; c++) {
+        // while the workers fill chunk c, retire the DMAs that have finished (their slots go back to the workers)
+        while (filled[c].load(std::memory_order_acquire) < T) {
+            if (retired < c && hipEventQuery(ev[retired % HC_NBUF]) == hipSuccess) freed.store(++retired, std::memory_order_release);
+            else std::this_thread::yield();
+        }
+        rc = hipMemcpyAsync((char *)dev + (size_t)c * HC_CHUNK, g_ring.buf[c % HC_NBUF], chunk_len(c), hipMemcpyHostToDevice, s);
+        if (rc == hipSuccess) rc = hipEventRecord(ev[c % HC_NBUF], s);
+        // a slot is needed for chunk c + 1 .. : if the ring is full, wait for the oldest DMA
+        if (rc == hipSuccess && c + 1 - retired >= HC_NBUF) {
+            rc = hipEventSynchronize(ev[retired % HC_NBUF]);
+            if (rc == hipSuccess) freed.store(++retired, std::memory_order_release);
+        }
+    }
+    if (rc != hipSuccess) stop.store(true, std::memory_order_relaxed);
+    for (auto &th : pool) th.join();
+    if (rc == hipSuccess) rc = hipStreamSynchronize(s);      // the ring is free again when the lock is released
+    (void)hipGetLastError();                                 // hipEventQuery's hipErrorNotReady is not an error of the call
+    for (int i = 0; i < HC_NBUF; i++) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // mcmchip_series_upload / mcmchip_series_free (include/mcmchip.h): a host matrix into HBM in the column-major layout the
 // diagnostics read, transposed on the device when the host holds it in C order.
@@ -140,10 +203,10 @@ extern "C" int mcmchip_series_upload(const double *x, int64_t n, int64_t p, int 
     HIP_TRY(out.alloc(bytes));
     hipStream_t s = dc->stream;
     if (!row_major || p == 1) {
-        HIP_TRY(hipMemcpyAsync(out.p, x, bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(copy_from_pageable_host(out.p, x, bytes, s));
     } else {
         HIP_TRY(raw.alloc(bytes));
-        HIP_TRY(hipMemcpyAsync(raw.p, x, bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(copy_from_pageable_host(raw.p, x, bytes, s));
         hipLaunchKernelGGL(transpose_rows_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((p + 63) / 64)), dim3(256), 0, s,
                            raw.as<double>(), (long)n, (long)p, out.as<double>());
         HIP_TRY(hipGetLastError());

@@ -176,7 +176,7 @@ def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api
             assert np.array_equal(got, ref), threads
 
 
-def test_series_upload_and_device_transpose(api, oracle_mod):
+def test_series_upload_and_device_transpose(api, oracle_mod, monkeypatch):
     """mcmchip_series_upload: a host matrix into HBM once, in the diagnostics' column-major layout, transposed on the
     device when the host holds it in C order (ragged 64 x 64 tiles included).  initseq / lagsums / olbm on the resident
     series give the bits of the host-pointer calls, and large C-ordered numpy arrays take that route by themselves."""
@@ -244,6 +244,31 @@ def test_series_upload_and_device_transpose(api, oracle_mod):
     rv, ref = api.initseq(v), oracle_mod.initseq(v - v.mean())
     assert len(rv["Gamma.pos"]) == len(ref["Gamma.pos"])
     assert abs(rv["var.con"] - ref["var.con"]) <= 1e-10 * abs(ref["var.con"])
+    # 64 MB and more go up through the pinned ring and host threads (hostcopy.hip): same bits with 8 threads, 1 thread and
+    # the plain copy, ragged last chunk included; as a host pointer (InBuf), as an upload, and as a design matrix
+    nb, pb = 1_200_007, 8
+    big = np.asfortranarray(rng.standard_normal((nb, pb)) + 1.0)
+    assert big.nbytes >= 64 << 20
+    mub = big.mean(axis=0)
+    Xb = rng.standard_normal((1_100_003, 8)); Xb[:, 0] = 1.0
+    yb = (rng.random(Xb.shape[0]) < 0.5).astype(float)
+    states = 0.1 * rng.standard_normal((70, 8))
+    want = None
+    for threads in (None, "1", "0"):
+        if threads is None:
+            monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("MCMCHIP_COPY_THREADS", threads)
+        ds = api.upload_series(big)
+        got = (api.olbm(big, 777, mean=mub), api.olbm(ds, 777, mean=mub), api.lagsums(np.ascontiguousarray(big), 8),
+               api.logdens(api.logistic_target(Xb, yb), states))
+        ds.free()
+        if want is None:
+            want = got
+        for g_, w_ in zip(got, want):
+            assert np.array_equal(g_, w_), threads
+    assert np.array_equal(want[0], want[1])
+    monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
     # bad arguments
     out = C.c_void_p()
     assert L.mcmchip_series_centre(None, 10, 2, None) == abi.EINVAL
