@@ -1,12 +1,4 @@
-// diag.hip -- Monte Carlo standard error estimators: initseq() and olbm().
-//
-// initseq (reference initseq.c:7-128): the O(len x lags) double sum of lag products
-// (initseq.c:24-47) is the hot loop; the monotone / convex post-processing (55-105) works on a
-// few hundred numbers and stays on the host, in the reference's own sequential order.
-//   autocov_kernel<NJ> computes NJ*16 consecutive lags of one column per work item on the fp64 matrix
-//   cores (v_mfma_f64_4x4x4_f64, every multiply-add of the instruction a wanted lag product; see the
-//   comment at the kernel).  Lags are produced speculatively in units of 64 because the stopping lag
-//   (first negative Gamma, initseq.c:42-46) is data dependent.  Partial sums are reduced in a fixed order.
+// diag.hip -- Monte Carlo standard error estimator olbm() (initseq lives in initseq.hip).
 //
 // olbm (reference olbm.c:22-78): sliding window sums and the p x p sum of outer products.
 //   p <= 256: olbm_mfma_kernel, all columns in one workgroup, var = V^T V on v_mfma_f64_16x16x4_f64 with
@@ -21,598 +13,6 @@
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
-
-// =============================================================================================
-// initseq
-// =============================================================================================
-#define IS_B 16                 // lags per work unit (one 16-lag accumulator per lane)
-#define IS_TILE 2048            // base positions per LDS tile
-#define IS_TILES_PER_BLOCK 32
-#define IS_MAXACC 48            // accumulators (16-lag blocks) per work item: at most 768 lags
-
-// Lag products on the fp64 matrix cores.  v_mfma_f64_4x4x4_f64 is four independent 4x4x4 products
-// (lane = q + 4*blk + 16*k: A_blk[i=q][k], B_blk[k][j=q]; result lane = j + 4*blk + 16*i; layout and a rate
-// equal to the 16x16x4 form measured by tools/mfma64_4x4_probe.hip).  With
-//     A_blk[i][k] = x[u + i + blk + 4k]          B_blk[k][j] = x[u + blk + 4k + 4j + 3 + L]
-// entry (i, j) accumulates x[t] * x[t + lag] for lag = L + 4j + 3 - i (16 consecutive lags) over the 16 base
-// positions t = u + i + (blk + 4k): every one of the 256 multiply-adds of the instruction is a wanted lag
-// product, and stepping u by 16 tiles the series exactly once.  Both operands are ~20 consecutive doubles
-// of one LDS image (conflict-free, mostly broadcast), and B(u + 16, L) = B(u, L + 16): a wave that walks u
-// in order keeps the B fragments of NJ lag blocks in registers and reads one new A and one new B fragment per
-// NJ MFMAs.  A workgroup stages a 2048-position tile in LDS, its 4 waves take 512 positions each, and the next
-// tile's global loads are in flight while this one is multiplied.
-// (initseq.c:24-47; the sums are the reference's up to summation order, and they do not depend on how the lags
-// are grouped into work items.)
-//
-// Round 2.  (1) ONE work item per column and launch round: NACC accumulators (16 lags each, up to 768 lags) are
-// worked off in pieces of 16 / 8 / 4 / 2 / 1 lag blocks over the SAME staged tile, so a column is streamed from
-// HBM once per round whatever its lag count (items of 64 and 256 lags used to re-read it per item; the short
-// columns, two thirds of C5, are HBM-bound).  (2) Every instruction of a wave that is not an MFMA is paid in
-// matrix-pipe time on gfx950, and the first version spent about a third of its time on the 64-bit index
-// arithmetic and range predicates of 18 guarded loads per thread and tile.  Now the tile is fetched through two
-// buffer descriptors rebuilt per tile in scalar registers: the hardware range check returns 0 past the end of
-// the series, the loads need no predicate and no per-lane address arithmetic beyond one precomputed byte
-// offset, and every load has an in-bounds LDS slot (the image is a whole number of 256-thread rounds).  Only the
-// first tile of a series, which starts 16 positions before element 0, takes guarded loads.  (3) When the
-// lag-shifted operand overlaps the base tile ONE contiguous image x[a .. a + 2048 + lag0 + 16 NACC + 35) serves
-// both operands (always so for the first lags of a column, the bulk of the work): half the loads and LDS writes.
-template <int NACC> struct AcShape {
-    static constexpr int NA = IS_TILE + 32, NB_ = IS_TILE + 16 * NACC + 32;
-    static constexpr int SA = (NA + 255) / 256, SB = (NB_ + 255) / 256;      // rounds of 256 loads per operand
-    static constexpr int NSLOT = SA + SB;
-};
-
-// the MFMAs of one piece: NJ lag blocks (any NJ <= 16) over this wave's 512 positions = 32 u-steps of the staged tile.
-// One A and one B fragment read per u-step serve NJ MFMAs; the B fragments of the last NJ steps sit in a register ring
-// that is back in phase after every NJ steps, so 32 steps are floor(32 / NJ) unrolled rounds plus a tail of 32 % NJ.
-template <int NJ, int NSTEP> __device__ __forceinline__ void autocov_round(const double *pa, const double *pb, int s0, double *R, double *acc)
-{
-#pragma unroll
-    for (int ss = 0; ss < NSTEP; ss++) {
-        const int s_ = s0 + ss;
-        const double fa = pa[16 * s_];
-        R[(ss + NJ - 1) % NJ] = pb[16 * (s_ + NJ - 1)];
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-            acc[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, R[(ss + j) % NJ], acc[j], 0, 0, 0);
-    }
-    // keep the fragment reads of a step next to the MFMAs of the step before it: left alone, the scheduler hoists
-    // all reads of the unrolled body to its top (64 VGPRs at NJ = 16, spills in the 768-lag kernel)
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int ss = 0; ss < NSTEP; ss++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    }
-}
-
-template <int NJ> __device__ __forceinline__ void autocov_piece(const double *pa, const double *pb, double *acc)
-{
-    constexpr int STEPS = IS_TILE / 4 / 16;           // 32 u-steps per wave and tile
-    double R[NJ];                                      // R[m % NJ] = B fragment at u + 16 m
-#pragma unroll
-    for (int m = 0; m < NJ - 1; m++) R[m] = pb[16 * m];
-    for (int s0 = 0; s0 + NJ <= STEPS; s0 += NJ) autocov_round<NJ, NJ>(pa, pb, s0, R, acc);
-    if constexpr (STEPS % NJ != 0) autocov_round<NJ, STEPS % NJ>(pa, pb, STEPS - STEPS % NJ, R, acc);
-}
-
-// NACC lag blocks as one piece up to 16, else as the fewest near-equal pieces (compile-time recursion: static
-// register indices)
-template <int NACC, int J0 = 0> __device__ __forceinline__ void autocov_pieces(const double *pa, const double *pb, double *acc)
-{
-    constexpr int REST = NACC - J0;
-    if constexpr (REST > 0) {
-        constexpr int NPIECE = (REST + 15) / 16;
-        constexpr int NJ = (REST + NPIECE - 1) / NPIECE;
-        autocov_piece<NJ>(pa, pb + 16 * J0, acc + J0);
-        autocov_pieces<NACC, J0 + NJ>(pa, pb, acc);
-    }
-}
-
-template <int NACC>
-__global__ __launch_bounds__(256, 2) void autocov_kernel(const double *__restrict__ x, long len, const int *__restrict__ cols,
-                                                      const long *__restrict__ lag_of, const int *__restrict__ unit_of,
-                                                      long nblk, int img_doubles, double *__restrict__ partial)
-{
-    using S = AcShape<NACC>;
-    constexpr int SA = S::SA, SB = S::SB, NSLOT = S::NSLOT;
-    extern __shared__ double ac_lds[];
-    double *P = ac_lds;                                   // [img_doubles] tile image(s)
-    double(*red)[16 * NACC] = (double(*)[16 * NACC])(ac_lds + img_doubles);   // [4][16 NACC]
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    // work item = (column, 16 NACC lags) on grid.x, time range on grid.y
-    const int col = cols[blockIdx.x];
-    const long lag0 = lag_of[blockIdx.x];
-    const double *xs = x + (size_t)col * len;
-    double acc[NACC];
-#pragma unroll
-    for (int j = 0; j < NACC; j++) acc[j] = 0.0;
-    const int q = lane & 3, blk = (lane >> 2) & 3, k = lane >> 4;
-    const int offA = q + blk + 4 * k, offB = blk + 4 * k + 4 * q;
-    // one image for both operands when the shifted one ends inside the padded image
-    const bool merged = lag0 + 3 + S::NB_ <= (long)NSLOT * 256;
-    const long shiftB = merged ? (long)SA * 256 : lag0 + 3;         // element offset of the second descriptor from the tile base
-    const double *pbase = merged ? P + (lag0 + 3) : P + SA * 256;   // where the lag-shifted operand starts in LDS
-    const long lenA = merged ? lag0 + 3 + S::NB_ : S::NA;            // elements the first descriptor may deliver (from the tile base)
-    const long lenB = merged ? lenA - (long)SA * 256 : S::NB_;       // ... and the second (from its own base)
-    const int nslot = merged ? (int)((lenA + 255) / 256) : NSLOT;    // rounds actually needed (wave-uniform)
-
-    double r[NSLOT];
-    const unsigned lane_off = (unsigned)t * 8u;
-    // descriptor over x[g .. g + cnt) of this column clipped to len: elements past the end come back as 0 from the
-    // hardware range check.  Only the very first tile of a series starts before element 0 (g = -16): that one
-    // takes guarded loads.
-    auto fetch_seg = [&](long g, long cnt, int slot0, int nseg) {
-        if (g < 0) {
-#pragma unroll
-            for (int i = 0; i < NSLOT; i++)
-                if (i >= slot0 && i < slot0 + nseg && i < nslot) {
-                    const long e = t + 256 * (i - slot0), idx = g + e;
-                    r[i] = (e < cnt && idx >= 0 && idx < len) ? xs[idx] : 0.0;
-                }
-            return;
-        }
-        long n_el = cnt;
-        if (g + n_el > len) n_el = len - g;
-        if (n_el < 0) n_el = 0;
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(xs + (g < len ? g : 0)), 0, (int)(unsigned)(n_el * 8), 0x00020000);
-#pragma unroll
-        for (int i = 0; i < NSLOT; i++)
-            if (i >= slot0 && i < slot0 + nseg && i < nslot)
-                r[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off + (unsigned)(i - slot0) * 2048u, 0, 0));
-    };
-    auto fetch = [&](long a) {
-        fetch_seg(a, lenA < (long)SA * 256 ? lenA : (long)SA * 256, 0, SA);
-        fetch_seg(a + shiftB, lenB, SA, SB);
-    };
-    const long first = (long)blockIdx.y * IS_TILES_PER_BLOCK * IS_TILE - 16;
-    fetch(first);
-    for (int tile = 0; tile < IS_TILES_PER_BLOCK; tile++) {
-        const long a = first + (long)tile * IS_TILE;
-        if (a >= len) break;
-        __syncthreads();                        // the previous tile's fragments are consumed
-#pragma unroll
-        for (int i = 0; i < NSLOT; i++)
-            if (i < nslot) P[t + 256 * i] = r[i];
-        __syncthreads();
-        if (tile + 1 < IS_TILES_PER_BLOCK && a + IS_TILE < len) fetch(a + IS_TILE);
-        autocov_pieces<NACC>(P + wave * (IS_TILE / 4) + offA, pbase + wave * (IS_TILE / 4) + offB, acc);
-    }
-    // the four blk groups of a wave, then the 4 waves in order
-#pragma unroll
-    for (int j = 0; j < NACC; j++) {
-        double v = acc[j];
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        if (blk == 0) red[wave][16 * j + 4 * q + 3 - k] = v;     // result lane = j' + 4*blk + 16*i: q = j', k = i
-    }
-    __syncthreads();
-    for (int e = t; e < 16 * NACC; e += 256) {
-        const double v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-        const int unit = unit_of[blockIdx.x] + e / IS_B;
-        partial[((size_t)unit * nblk + blockIdx.y) * IS_B + e % IS_B] = v;
-    }
-}
-
-// sums the per-time-block partials of one 16-lag unit in a fixed order: 16 lanes per lag take the blocks
-// b = part, part + 16, ... each, then the 16 part sums are added in order (reruns give the same bits)
-__global__ __launch_bounds__(256) void autocov_reduce_kernel(const double *__restrict__ partial, long nblk, double *__restrict__ out)
-{
-    __shared__ double part_sum[16][IS_B];
-    const int k = threadIdx.x % IS_B, part = threadIdx.x / IS_B;      // IS_B = 16: 16 parts x 16 lags
-    const double *p = partial + (size_t)blockIdx.x * nblk * IS_B + k;
-    double s = 0.0;
-    for (long b = part; b < nblk; b += 16) s += p[b * IS_B];
-    part_sum[part][k] = s;
-    __syncthreads();
-    if (part == 0) {
-        double v = 0.0;
-        for (int j = 0; j < 16; j++) v += part_sum[j][k];
-        out[(size_t)blockIdx.x * IS_B + k] = v;
-    }
-}
-
-// Host post-processing of one column's Gamma sequence (a few hundred numbers).  What initseq.c:49-105 returns:
-//   Gamma.pos  the sequence as computed (truncated at the first negative term, which is stored as 0),
-//   Gamma.dec  its greatest non-increasing minorant = running minimum,
-//   Gamma.con  its greatest convex minorant: isotonic regression (pool adjacent violators) of the slopes of
-//              Gamma.dec, integrated back from Gamma.dec[0],
-//   var.*      2 * sum(Gamma.*) - gamma0.
-// The pooled slopes are kept as a stack of {sum, count} blocks; block means are compared as sum / count and
-// merged by adding sums, and the convex sequence is rebuilt by repeated addition of the block mean: the same
-// floating-point operations in the same order as the reference, so results agree bit for bit with its arithmetic.
-namespace {
-struct SlopeBlock {
-    double sum;     // sum of the slopes pooled into this block
-    long count;     // how many
-    double mean() const { return sum / count; }
-};
-
-struct GammaOut {
-    double *pos, *dec, *con;
-    double *var_pos, *var_dec, *var_con;
-};
-
-double twice_sum_minus(const double *v, long m, double g0)
-{
-    double s = 0.0;
-    for (long j = 0; j < m; ++j) s += v[j];
-    return 2.0 * s - g0;
-}
-
-void gamma_sequences(const double *G, long m, double g0, const GammaOut &o)
-{
-    if (m > 0) {
-        // running minimum
-        double low = G[0];
-        for (long j = 0; j < m; ++j) {
-            o.pos[j] = G[j];
-            if (!(G[j] > low)) low = G[j];
-            o.dec[j] = low;
-        }
-        // isotonic regression of the slopes dec[j] - dec[j-1], j = 1..m-1, by pooling adjacent violators
-        std::vector<SlopeBlock> pool;
-        pool.reserve((size_t)m);
-        for (long j = 1; j < m; ++j) {
-            pool.push_back(SlopeBlock{o.dec[j] - o.dec[j - 1], 1});
-            while (pool.size() > 1 && pool.back().mean() < pool[pool.size() - 2].mean()) {
-                const SlopeBlock top = pool.back();
-                pool.pop_back();
-                pool.back().sum += top.sum;
-                pool.back().count += top.count;
-            }
-        }
-        // integrate the pooled slopes back
-        o.con[0] = o.dec[0];
-        long j = 1;
-        for (const SlopeBlock &b : pool) {
-            const double slope = b.mean();
-            for (long r = 0; r < b.count; ++r, ++j) o.con[j] = o.con[j - 1] + slope;
-        }
-    }
-    *o.var_pos = twice_sum_minus(o.pos, m, g0);
-    *o.var_dec = twice_sum_minus(o.dec, m, g0);
-    *o.var_con = twice_sum_minus(o.con, m, g0);
-}
-}  // namespace
-
-// one launch round of lag products: one work item per column (more only beyond 768 lags), grouped by accumulator
-// count into launches; partial sums per time block, the fixed-order reduction over the time blocks, and the sums
-// back on the host
-namespace {
-const int kAccSizes[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 32, 48};      // instantiated NACC
-const int kNumAccSizes = (int)(sizeof kAccSizes / sizeof kAccSizes[0]);
-
-struct LagRound {
-    std::vector<int> unit_col;                                  // per 16-lag unit, in (column, lag) order
-    std::vector<int> item_col[kNumAccSizes], item_unit[kNumAccSizes];
-    std::vector<long> item_lag[kNumAccSizes];
-    void clear()
-    {
-        unit_col.clear();
-        for (int w = 0; w < kNumAccSizes; w++) { item_col[w].clear(); item_unit[w].clear(); item_lag[w].clear(); }
-    }
-    // at least nb units (16 lags each) of column c from lag0 on: one item of the next instantiated size, or several
-    // beyond IS_MAXACC.  Returns the units actually scheduled.
-    long add(int c, long lag0, long nb)
-    {
-        long done = 0;
-        while (done < nb) {
-            const long rest = nb - done;
-            int w = kNumAccSizes - 1;
-            if (rest < IS_MAXACC) { w = 0; while (kAccSizes[w] < rest) w++; }
-            item_col[w].push_back(c);
-            item_unit[w].push_back((int)unit_col.size());
-            item_lag[w].push_back(lag0 + done * IS_B);
-            for (int u = 0; u < kAccSizes[w]; u++) unit_col.push_back(c);
-            done += kAccSizes[w];
-        }
-        return done;
-    }
-};
-
-struct LagBuffers {
-    DevBuf partial, sums, dcols, dlags, dunits;
-    size_t cap_units = 0, cap_blocks = 0;
-};
-
-template <int NACC>
-int launch_autocov(dim3 grid, hipStream_t s, const double *x, long len, const int *pc, const long *pl, const int *pu,
-                   long nblk, bool all_first_lags, double *pp)
-{
-    using S = AcShape<NACC>;
-    // LDS: the tile image -- when every item of the launch starts at lag 0 the two operands share one image of
-    // 2048 + 16 NACC + 35 positions -- and the [4][16 NACC] cross-wave reduction
-    const int img = all_first_lags ? ((3 + S::NB_ + 255) / 256) * 256 : S::NSLOT * 256;
-    const size_t lds = ((size_t)img + 4 * 16 * NACC) * 8;
-    auto kern = autocov_kernel<NACC>;
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, len, pc, pl, pu, nblk, img, pp);
-    return MCMCHIP_OK;
-}
-
-// runs the round over time blocks [0, nblk_run) and leaves unit_col.size() * IS_B sums in `host`
-int run_lag_round(const double *x, long len, long nblk_run, const LagRound &w, LagBuffers &B, std::vector<double> &host,
-                  DeviceCtx *dc)
-{
-    hipStream_t s = dc->stream;
-    const size_t nunit = w.unit_col.size();
-    if (nunit > B.cap_units || (size_t)nblk_run > B.cap_blocks) {       // sizes follow the work list
-        B.partial.release(); B.sums.release(); B.dcols.release(); B.dlags.release(); B.dunits.release();
-        B.cap_units = nunit > B.cap_units ? nunit : B.cap_units;
-        B.cap_blocks = (size_t)nblk_run > B.cap_blocks ? (size_t)nblk_run : B.cap_blocks;
-        HIP_TRY(B.partial.alloc(B.cap_units * B.cap_blocks * IS_B * 8));
-        HIP_TRY(B.sums.alloc(B.cap_units * IS_B * 8));
-        HIP_TRY(B.dcols.alloc(B.cap_units * sizeof(int)));
-        HIP_TRY(B.dlags.alloc(B.cap_units * sizeof(long)));
-        HIP_TRY(B.dunits.alloc(B.cap_units * sizeof(int)));
-    }
-    // the item lists first, then the launches on two side streams: items of few lags are HBM-bound (one pass over the
-    // column for 32-64 lags), items of many lags MFMA-bound; run side by side they fill both resources
-    size_t off = 0;
-    size_t offs[kNumAccSizes];
-    for (int k = kNumAccSizes - 1; k >= 0; k--) {
-        const size_t ni = w.item_col[k].size();
-        offs[k] = off;
-        if (!ni) continue;
-        HIP_TRY(hipMemcpyAsync(B.dcols.as<int>() + off, w.item_col[k].data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(B.dlags.as<long>() + off, w.item_lag[k].data(), ni * sizeof(long), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(B.dunits.as<int>() + off, w.item_unit[k].data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
-        off += ni;
-    }
-    const bool overlap = getenv("MCMCHIP_INITSEQ_OVERLAP") != nullptr;   // measured at full C5 size: no gain (span 117.7 ms vs 111 ms serial), off by default
-    if (overlap) {
-        HIP_TRY(hipEventRecord(dc->fork_ev, s));
-        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(dc->side[i], dc->fork_ev, 0));
-    }
-    for (int k = kNumAccSizes - 1; k >= 0; k--) {                 // the long items first
-        const size_t ni = w.item_col[k].size();
-        if (!ni) continue;
-        hipStream_t ls = overlap ? dc->side[kAccSizes[k] >= 5 ? 0 : 1] : s;
-        dim3 grid((unsigned)ni, (unsigned)nblk_run);
-        const int *pc = B.dcols.as<int>() + offs[k], *pu = B.dunits.as<int>() + offs[k];
-        const long *pl = B.dlags.as<long>() + offs[k];
-        double *pp = B.partial.as<double>();
-        bool first_lags = true;
-        for (long l : w.item_lag[k]) first_lags = first_lags && l == 0;
-        int rc = MCMCHIP_OK;
-        timing_begin(ls);
-        switch (kAccSizes[k]) {
-#define AC_CASE(N) case N: rc = launch_autocov<N>(grid, ls, x, len, pc, pl, pu, nblk_run, first_lags, pp); break;
-        AC_CASE(1) AC_CASE(2) AC_CASE(3) AC_CASE(4) AC_CASE(5) AC_CASE(6) AC_CASE(7) AC_CASE(8) AC_CASE(10) AC_CASE(12)
-        AC_CASE(14) AC_CASE(16) AC_CASE(20) AC_CASE(24) AC_CASE(32) AC_CASE(48)
-#undef AC_CASE
-        default: rc = set_error(MCMCHIP_EINVAL, "initseq: no kernel for %d accumulators", kAccSizes[k]);
-        }
-        timing_end(ls);
-        if (rc) return rc;
-        HIP_TRY(hipGetLastError());
-    }
-    if (overlap)
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipEventRecord(dc->join_ev[i], dc->side[i]));
-            HIP_TRY(hipStreamWaitEvent(s, dc->join_ev[i], 0));
-        }
-    const long total = (long)nunit * IS_B;
-    static_assert(IS_B == 16, "autocov_reduce_kernel splits 256 threads into 16 parts x 16 lags");
-    hipLaunchKernelGGL(autocov_reduce_kernel, dim3((unsigned)nunit), dim3(256), 0, s, B.partial.as<double>(), nblk_run,
-                       B.sums.as<double>());
-    HIP_TRY(hipGetLastError());
-    host.resize((size_t)total);
-    HIP_TRY(hipMemcpyAsync(host.data(), B.sums.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return MCMCHIP_OK;
-}
-
-// Where will the stop rule fire?  Gamma_k of a geometrically mixing chain decays like r^k and the rule (first
-// negative Gamma, initseq.c:42-46) fires once the sequence reaches its noise floor, about Gamma_0 / sqrt(len):
-// the decay is read off the part of the sequence that is still well above the noise (>= 10 % of Gamma_0) and
-// extrapolated.  Returns the expected number of lag PAIRS; only the amount of speculative work depends on it.
-double predict_pairs(const double *G, long m, long len)
-{
-    if (m < 2 || !(G[0] > 0.0)) return 1.0;
-    long j = 0;
-    while (j + 1 < m && G[j + 1] > 0.1 * G[0] && G[j + 1] < G[j]) j++;
-    if (j == 0) {
-        if (!(G[1] > 0.0) || !(G[1] < G[0])) return 2.0;
-        j = 1;
-    }
-    const double decay = std::log(G[0] / G[j]) / (double)j;        // per lag pair
-    return 0.5 * std::log((double)len) / decay;
-}
-}  // namespace
-
-#define IS_MAX_UNITS_PER_LAUNCH 64      // at most 1024 new lags per column and round
-#define IS_PILOT_BLOCKS 32              // pilot pass: the first 32 * 65536 positions of every column
-
-int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0, double *Gpos,
-                double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon, DeviceCtx *dc)
-{
-    const long half = len / 2;
-    // tiles start at position -16 (zero padded), so the 4 result rows of an MFMA see every base position
-    const long span = (long)IS_TILE * IS_TILES_PER_BLOCK;
-    const long nblk = (len + 16 + span - 1) / span;
-    if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
-    // The stopping lag is data dependent, so lags are produced speculatively in units of 16.  Long series start
-    // with a PILOT: 64 lags of every column over its first 2M positions only (~1 % of a pass), whose Gamma
-    // sequence predicts where the stop rule will fire; the first full pass then asks each column for that many
-    // lags plus a margin, so most columns need one pass over HBM.  A column that is still active afterwards gets
-    // 20 % more lags per further round.  The sums themselves do not depend on any of this.
-    const bool trace = getenv("MCMCHIP_TRACE") != nullptr;
-    LagBuffers bufs;
-    LagRound work;
-    std::vector<std::vector<double>> Gam((size_t)ncol);   // Gamma_i per column, as far as computed
-    std::vector<long> done((size_t)ncol, -1);            // output length once the stop rule fired
-    std::vector<long> have((size_t)ncol, 0);             // lags computed so far
-    std::vector<double> g0((size_t)ncol, 0.0);
-    std::vector<double> guess((size_t)ncol, 0.0);        // predicted lag pairs
-    std::vector<int> rounds((size_t)ncol, 0);            // full-length launches a column has taken part in
-    std::vector<int> active;
-    for (long c = 0; c < ncol; c++) active.push_back((int)c);
-    std::vector<double> host;
-    timing_reset("autocov_kernel");
-    if (half == 0) active.clear();
-    const long npilot = nblk >= 16 ? (nblk / 64 < 1 ? 1 : (nblk / 64 > IS_PILOT_BLOCKS ? IS_PILOT_BLOCKS : nblk / 64)) : 0;
-    if (npilot > 0 && !active.empty()) {
-        work.clear();
-        for (int c : active) work.add(c, 0, 64 / IS_B);
-        if (int rc = run_lag_round(x, len, npilot, work, bufs, host, dc)) return rc;
-        std::vector<double> G(32);
-        for (size_t a = 0; a < active.size(); a++) {
-            const double *g = host.data() + a * 64;
-            for (int j = 0; j < 32; j++) G[(size_t)j] = g[2 * j] + g[2 * j + 1];
-            guess[(size_t)active[a]] = predict_pairs(G.data(), 32, len);
-        }
-        if (trace) fprintf(stderr, "[initseq] pilot: %zu columns x 64 lags over %ld of %ld time blocks\n", active.size(), npilot, nblk);
-    }
-    while (!active.empty()) {
-        work.clear();
-        for (int c : active) {
-            const long h = have[(size_t)c];
-            long nb;
-            if (rounds[(size_t)c] == 0 && npilot == 0) {
-                nb = 64 / IS_B;                                      // no pilot: 64 full-length lags are the prediction
-            } else if (rounds[(size_t)c] == 0 || (rounds[(size_t)c] == 1 && npilot == 0)) {
-                // The first pass sized by the prediction.  Measured at C5 size the stop comes at 0.7 ... 2 x the
-                // prediction (median 1.18, upper decile 1.76: the rule fires in the noise).  A column of few lags is
-                // HBM-bound and a second pass over it costs as much as the first, so it gets a generous margin; a
-                // column of many lags is MFMA-bound, every extra lag costs, and a further round is cheap by comparison.
-                const double p = npilot > 0 ? guess[(size_t)c] : predict_pairs(Gam[(size_t)c].data(), (long)Gam[(size_t)c].size(), len);
-                const double f = p <= 16.0 ? 1.7 : (p <= 40.0 ? 1.4 : (p <= 150.0 ? 1.15 : 1.05));
-                const double want = 2.0 * p * f + 4.0 - (double)h;
-                nb = want > 0.0 ? (long)std::ceil(want / IS_B) : 1;
-            } else {
-                nb = (long)std::ceil(0.2 * (double)h / IS_B);      // overshoot of the stop rule into the noise
-            }
-            if (nb < 1) nb = 1;
-            rounds[(size_t)c]++;
-            if (nb > IS_MAX_UNITS_PER_LAUNCH) nb = IS_MAX_UNITS_PER_LAUNCH;
-            const long need = (2 * half - h + IS_B - 1) / IS_B;    // never past lag 2*half
-            if (nb > need) nb = need;
-            work.add(c, h, nb);
-        }
-        const long nitem = (long)work.unit_col.size();         // units
-        if (trace)
-        {
-            fprintf(stderr, "[initseq] round: %zu active columns, %ld units of %d lags, %ld time blocks; items x lags:", active.size(), nitem, IS_B, nblk);
-            for (int k = 0; k < kNumAccSizes; k++)
-                if (!work.item_col[k].empty()) fprintf(stderr, " %zu x %d", work.item_col[k].size(), 16 * kAccSizes[k]);
-            fprintf(stderr, "\n");
-        }
-        if (int rc = run_lag_round(x, len, nblk, work, bufs, host, dc)) return rc;
-        const std::vector<int> &item_col_flat = work.unit_col;
-        std::vector<int> next;
-        long it = 0;
-        for (int c : active) {
-            long nb = 0;
-            while (it + nb < nitem && item_col_flat[(size_t)(it + nb)] == c) nb++;
-            const double *g = host.data() + (size_t)it * IS_B;    // lags have[c] .. have[c] + nb*16
-            const long lag_first = have[(size_t)c];
-            bool fin = false;
-            for (long q = 0; q < nb * IS_B / 2 && !fin; q++) {
-                const long i = lag_first / 2 + q;
-                if (i >= half) { done[(size_t)c] = half; fin = true; break; }
-                const double gam1 = g[2 * q] / len, gam2 = g[2 * q + 1] / len;    // initseq.c:30,39
-                if (i == 0) {
-                    g0[(size_t)c] = gam1;
-                    // the lag-0 sum of squares is finite iff every element is (short of overflow): this is where a
-                    // series handed over as a device pointer gets the reference's finiteness check (initseq.c:15)
-                    if (!std::isfinite(gam1)) {
-                        int bits = 0;
-                        if (int rc = device_validate(dc, x + (size_t)c * len, len, 1, 0, &bits)) return rc;
-                        if (bits) return set_error(MCMCHIP_EINVAL, "all elements of argument must be finite");
-                        return set_error(MCMCHIP_EDOMAIN, "initseq: the lag-0 sum of squares of column %ld overflows", (long)c);
-                    }
-                }
-                double G = gam1 + gam2;
-                if (G < 0.0) {                                                    // initseq.c:42-46
-                    Gam[(size_t)c].push_back(0.0);
-                    done[(size_t)c] = i + 1;
-                    fin = true;
-                } else {
-                    Gam[(size_t)c].push_back(G);
-                    if (i + 1 >= half) { done[(size_t)c] = half; fin = true; }
-                }
-            }
-            have[(size_t)c] += nb * IS_B;
-            it += nb;
-            if (!fin) next.push_back(c);
-            else if (trace && getenv("MCMCHIP_TRACE")[0] == '2')
-                fprintf(stderr, "[initseq] column %d: predicted %.1f pairs, stopped at %ld, computed %ld lags in %d rounds\n",
-                        c, guess[(size_t)c], done[(size_t)c], have[(size_t)c], rounds[(size_t)c]);
-        }
-        active.swap(next);
-    }
-    bool overflow = false;
-    for (long c = 0; c < ncol; c++) {
-        long m = half == 0 ? 0 : done[(size_t)c];
-        n_out[c] = m;
-        gamma0[c] = g0[(size_t)c];
-        if (m > cap) { overflow = true; continue; }
-        gamma_sequences(Gam[(size_t)c].data(), m, g0[(size_t)c],
-                        GammaOut{Gpos + (size_t)c * cap, Gdec + (size_t)c * cap, Gcon + (size_t)c * cap, vpos + c, vdec + c, vcon + c});
-    }
-    if (overflow) return set_error(MCMCHIP_ECAP, "initseq: output capacity too small; required lengths are in n_out");
-    return MCMCHIP_OK;
-}
-
-// raw lag sums sum_t x[t] x[t + l], l = 0 .. nlags-1, of every column over the whole array given (zero beyond its end):
-// what a time-sharded initseq all-reduces (mcmc_amd/dist.py::initseq_time_sharded)
-int run_lagsums(const double *x, long len, long ncol, long nlags, double *sums, DeviceCtx *dc)
-{
-    const long span = (long)IS_TILE * IS_TILES_PER_BLOCK;
-    const long nblk = (len + 16 + span - 1) / span;
-    if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
-    const long units = (nlags + IS_B - 1) / IS_B;
-    LagBuffers bufs;
-    LagRound work;
-    std::vector<long> first((size_t)ncol);
-    for (long c = 0; c < ncol; c++) {
-        first[(size_t)c] = (long)work.unit_col.size();
-        work.add((int)c, 0, units);
-    }
-    std::vector<double> host;
-    timing_reset("autocov_kernel");
-    if (int rc = run_lag_round(x, len, nblk, work, bufs, host, dc)) return rc;
-    for (long c = 0; c < ncol; c++)
-        for (long l = 0; l < nlags; l++) sums[(size_t)c * nlags + l] = host[(size_t)first[(size_t)c] * IS_B + l];
-    return MCMCHIP_OK;
-}
-
-// the stop rule and the three sequences from TOTAL lag sums (host only; initseq.c:24-105 on sums computed elsewhere).
-// n_out[c] = -1 when column c has not reached its stopping lag within nlags: the caller comes back with more lags.
-int run_initseq_from_lagsums(const double *sums, long len, long ncol, long nlags, long cap, long *n_out, double *gamma0,
-                             double *Gpos, double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon)
-{
-    const long half = len / 2;
-    bool overflow = false;
-    std::vector<double> G;
-    for (long c = 0; c < ncol; c++) {
-        const double *g = sums + (size_t)c * nlags;
-        G.clear();
-        long m = -1;
-        double g0 = 0.0;
-        if (half == 0) m = 0;
-        for (long i = 0; m < 0 && 2 * i + 1 < nlags; i++) {
-            if (i >= half) { m = half; break; }
-            const double gam1 = g[2 * i] / len, gam2 = g[2 * i + 1] / len;        // initseq.c:30,39
-            if (i == 0) g0 = gam1;
-            const double Gi = gam1 + gam2;
-            if (Gi < 0.0) { G.push_back(0.0); m = i + 1; }                        // initseq.c:42-46
-            else { G.push_back(Gi); if (i + 1 >= half) m = half; }
-        }
-        gamma0[c] = nlags > 0 ? g[0] / len : 0.0;
-        n_out[c] = m;
-        if (m < 0) continue;
-        if (m > cap) { overflow = true; continue; }
-        gamma_sequences(G.data(), m, g0, GammaOut{Gpos + (size_t)c * cap, Gdec + (size_t)c * cap, Gcon + (size_t)c * cap,
-                                                   vpos + c, vdec + c, vcon + c});
-    }
-    if (overflow) return set_error(MCMCHIP_ECAP, "initseq: output capacity too small; required lengths are in n_out");
-    return MCMCHIP_OK;
-}
 
 // =============================================================================================
 // olbm
@@ -1368,3 +768,4 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
     HIP_TRY(hipStreamSynchronize(s));
     return MCMCHIP_OK;
 }
+

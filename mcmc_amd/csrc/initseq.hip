@@ -1,0 +1,465 @@
+// initseq.hip -- Monte Carlo standard error estimator initseq() (reference initseq.c:7-128).
+//
+// The O(len x lags) double sum of lag products (initseq.c:24-47) is the hot loop; the monotone / convex
+// post-processing (55-105) works on a few hundred numbers and stays on the host, in the reference's own
+// sequential order.  autocov kernels compute 16 NACC consecutive lags of one column per work item on the fp64
+// matrix cores (v_mfma_f64_4x4x4_f64, every multiply-add of the instruction a wanted lag product; see the comment
+// at the kernel).  Lags are produced speculatively because the stopping lag (first negative Gamma,
+// initseq.c:42-46) is data dependent.  Partial sums are reduced in a fixed order.
+#include "kernels.h"
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+
+// =============================================================================================
+// initseq
+// =============================================================================================
+#include "initseq_kernels.h"
+
+// sums the per-time-block partials of one 16-lag unit in a fixed order: 16 lanes per lag take the blocks
+// b = part, part + 16, ... each, then the 16 part sums are added in order (reruns give the same bits)
+__global__ __launch_bounds__(256) void autocov_reduce_kernel(const double *__restrict__ partial, long nblk, double *__restrict__ out)
+{
+    __shared__ double part_sum[16][IS_B];
+    const int k = threadIdx.x % IS_B, part = threadIdx.x / IS_B;      // IS_B = 16: 16 parts x 16 lags
+    const double *p = partial + (size_t)blockIdx.x * nblk * IS_B + k;
+    double s = 0.0;
+    for (long b = part; b < nblk; b += 16) s += p[b * IS_B];
+    part_sum[part][k] = s;
+    __syncthreads();
+    if (part == 0) {
+        double v = 0.0;
+        for (int j = 0; j < 16; j++) v += part_sum[j][k];
+        out[(size_t)blockIdx.x * IS_B + k] = v;
+    }
+}
+
+// Host post-processing of one column's Gamma sequence (a few hundred numbers).  What initseq.c:49-105 returns:
+//   Gamma.pos  the sequence as computed (truncated at the first negative term, which is stored as 0),
+//   Gamma.dec  its greatest non-increasing minorant = running minimum,
+//   Gamma.con  its greatest convex minorant: isotonic regression (pool adjacent violators) of the slopes of
+//              Gamma.dec, integrated back from Gamma.dec[0],
+//   var.*      2 * sum(Gamma.*) - gamma0.
+// The pooled slopes are kept as a stack of {sum, count} blocks; block means are compared as sum / count and
+// merged by adding sums, and the convex sequence is rebuilt by repeated addition of the block mean: the same
+// floating-point operations in the same order as the reference, so results agree bit for bit with its arithmetic.
+namespace {
+struct SlopeBlock {
+    double sum;     // sum of the slopes pooled into this block
+    long count;     // how many
+    double mean() const { return sum / count; }
+};
+
+struct GammaOut {
+    double *pos, *dec, *con;
+    double *var_pos, *var_dec, *var_con;
+};
+
+double twice_sum_minus(const double *v, long m, double g0)
+{
+    double s = 0.0;
+    for (long j = 0; j < m; ++j) s += v[j];
+    return 2.0 * s - g0;
+}
+
+void gamma_sequences(const double *G, long m, double g0, const GammaOut &o)
+{
+    if (m > 0) {
+        // running minimum
+        double low = G[0];
+        for (long j = 0; j < m; ++j) {
+            o.pos[j] = G[j];
+            if (!(G[j] > low)) low = G[j];
+            o.dec[j] = low;
+        }
+        // isotonic regression of the slopes dec[j] - dec[j-1], j = 1..m-1, by pooling adjacent violators
+        std::vector<SlopeBlock> pool;
+        pool.reserve((size_t)m);
+        for (long j = 1; j < m; ++j) {
+            pool.push_back(SlopeBlock{o.dec[j] - o.dec[j - 1], 1});
+            while (pool.size() > 1 && pool.back().mean() < pool[pool.size() - 2].mean()) {
+                const SlopeBlock top = pool.back();
+                pool.pop_back();
+                pool.back().sum += top.sum;
+                pool.back().count += top.count;
+            }
+        }
+        // integrate the pooled slopes back
+        o.con[0] = o.dec[0];
+        long j = 1;
+        for (const SlopeBlock &b : pool) {
+            const double slope = b.mean();
+            for (long r = 0; r < b.count; ++r, ++j) o.con[j] = o.con[j - 1] + slope;
+        }
+    }
+    *o.var_pos = twice_sum_minus(o.pos, m, g0);
+    *o.var_dec = twice_sum_minus(o.dec, m, g0);
+    *o.var_con = twice_sum_minus(o.con, m, g0);
+}
+}  // namespace
+
+// one launch round of lag products: one work item per column (more only beyond 768 lags), grouped by kernel variant
+// into launches; partial sums per time block, the fixed-order reduction over the time blocks, and the sums back on
+// the host
+namespace {
+// instantiated kernels: items that start at lag 0 (initseq_first_a/b.hip; fine steps, because the unit count of an
+// item is rounded up to the next one and these carry > 90 % of the work: 33 units used to run as 48) and
+// continuation items (initseq_cont.hip)
+struct Variant { int nacc; bool first; };
+const Variant kVariants[] = {
+    {1, true}, {2, true}, {3, true}, {4, true}, {5, true}, {6, true}, {7, true}, {8, true}, {9, true}, {10, true},
+    {11, true}, {12, true}, {13, true}, {14, true}, {16, true}, {18, true}, {20, true}, {22, true}, {24, true},
+    {28, true}, {32, true}, {36, true}, {40, true}, {44, true}, {48, true},
+    {1, false}, {2, false}, {3, false}, {4, false}, {6, false}, {8, false}, {12, false}, {16, false}, {24, false},
+    {32, false}};
+const int kNumVariants = (int)(sizeof kVariants / sizeof kVariants[0]);
+
+// time blocks: a workgroup walks `tpb` tiles of IS_TILE positions; a function of the length of the series alone, so
+// the summation order -- and with it every bit of the result -- does not depend on what else a call computes
+struct TimeGrid {
+    long tpb, nblk, span;
+    explicit TimeGrid(long len)
+    {
+        const long ntiles = (len + 16 + IS_TILE - 1) / IS_TILE;
+        tpb = ntiles / 256;
+        if (tpb < 1) tpb = 1;
+        if (tpb > 64) tpb = 64;
+        span = tpb * IS_TILE;
+        nblk = (len + 16 + span - 1) / span;
+    }
+};
+
+struct LagRound {
+    struct Item { int col, unit; long lag; };
+    std::vector<int> unit_col;                                  // per 16-lag unit, in (column, lag) order
+    std::vector<Item> items[kNumVariants];
+    void clear()
+    {
+        unit_col.clear();
+        for (int w = 0; w < kNumVariants; w++) items[w].clear();
+    }
+    // at least nb units (16 lags each) of column c from lag0 on: one item of the next instantiated size of its
+    // family, or several beyond IS_MAXACC.  Returns the units actually scheduled.
+    long add(int c, long lag0, long nb)
+    {
+        long done = 0;
+        while (done < nb) {
+            const long rest = nb - done, lag = lag0 + done * IS_B;
+            const bool first = lag == 0;
+            int w = -1;                                     // the family's first size that covers the rest, else its largest
+            for (int v = 0; v < kNumVariants; v++)
+                if (kVariants[v].first == first) {
+                    w = v;
+                    if (kVariants[v].nacc >= rest) break;
+                }
+            items[w].push_back(Item{c, (int)unit_col.size(), lag});
+            for (int u = 0; u < kVariants[w].nacc; u++) unit_col.push_back(c);
+            done += kVariants[w].nacc;
+        }
+        return done;
+    }
+};
+
+struct LagBuffers {
+    DevBuf partial, sums, lists;
+    size_t cap_units = 0, cap_blocks = 0;
+    std::vector<char> host_lists;
+};
+
+// runs the round over time blocks [0, nblk_run) and leaves unit_col.size() * IS_B sums in `host`
+int run_lag_round(const double *x, long len, const TimeGrid &tg, long nblk_run, const LagRound &w, LagBuffers &B,
+                  std::vector<double> &host, DeviceCtx *dc)
+{
+    hipStream_t s = dc->stream;
+    const size_t nunit = w.unit_col.size();
+    if (nunit > B.cap_units || (size_t)nblk_run > B.cap_blocks) {       // sizes follow the work list
+        B.partial.release(); B.sums.release(); B.lists.release();
+        B.cap_units = nunit > B.cap_units ? nunit : B.cap_units;
+        B.cap_blocks = (size_t)nblk_run > B.cap_blocks ? (size_t)nblk_run : B.cap_blocks;
+        HIP_TRY(B.partial.alloc(B.cap_units * B.cap_blocks * IS_B * 8));
+        HIP_TRY(B.sums.alloc(B.cap_units * IS_B * 8));
+        HIP_TRY(B.lists.alloc(B.cap_units * 16));
+    }
+    // the item lists of all launches in one upload: lags (long), then columns, then first units (int), each in launch order
+    size_t nitem = 0, offs[kNumVariants];
+    for (int v = 0; v < kNumVariants; v++) { offs[v] = nitem; nitem += w.items[v].size(); }
+    B.host_lists.resize(nitem * 16);
+    long *hl = (long *)B.host_lists.data();
+    int *hc = (int *)(hl + nitem), *hu = hc + nitem;
+    for (int v = 0; v < kNumVariants; v++)
+        for (size_t i = 0; i < w.items[v].size(); i++) {
+            hl[offs[v] + i] = w.items[v][i].lag;
+            hc[offs[v] + i] = w.items[v][i].col;
+            hu[offs[v] + i] = w.items[v][i].unit;
+        }
+    if (nitem) HIP_TRY(hipMemcpyAsync(B.lists.p, B.host_lists.data(), nitem * 16, hipMemcpyHostToDevice, s));
+    const long *dl = B.lists.as<long>();
+    const int *dcol = (const int *)(dl + nitem), *dunit = dcol + nitem;
+    // the launches, long items first.  MCMCHIP_INITSEQ_OVERLAP=1 puts the MFMA-bound and the HBM-bound ones on two
+    // side streams (measured at full C5 size in round 2: no gain, span 117.7 ms vs 111 ms serial; off by default)
+    const bool overlap = getenv("MCMCHIP_INITSEQ_OVERLAP") != nullptr;
+    const int overlap_mode = overlap ? atoi(getenv("MCMCHIP_INITSEQ_OVERLAP")) : 0;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(dc->fork_ev, s));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(dc->side[i], dc->fork_ev, 0));
+    }
+    int order[kNumVariants];
+    for (int v = 0; v < kNumVariants; v++) order[v] = v;
+    const bool descending = getenv("MCMCHIP_INITSEQ_DESCENDING") != nullptr;
+    for (int i = 1; i < kNumVariants; i++)                                 // by accumulator count
+        for (int j = i; j > 0 && (descending ? kVariants[order[j]].nacc > kVariants[order[j - 1]].nacc
+                                             : kVariants[order[j]].nacc < kVariants[order[j - 1]].nacc); j--) {
+            const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp;
+        }
+    for (int o = 0; o < kNumVariants; o++) {
+        const int v = order[o];
+        const size_t ni = w.items[v].size();
+        if (!ni) continue;
+        const int nacc = kVariants[v].nacc;
+        hipStream_t ls = !overlap ? s : (overlap_mode == 2 ? dc->side[o & 1] : dc->side[nacc >= 5 ? 0 : 1]);
+        dim3 grid((unsigned)ni, (unsigned)nblk_run);
+        long img = 0;
+        if (!kVariants[v].first)
+            for (const LagRound::Item &it : w.items[v]) {
+                const long need = autocov_cont_image(nacc, it.lag);
+                if (need > img) img = need;
+            }
+        int rc;
+        timing_begin(ls);
+        if (!kVariants[v].first)
+            rc = launch_autocov_cont(nacc, grid, ls, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, (int)img, B.partial.as<double>());
+        else if ((rc = launch_autocov_first_a(nacc, grid, ls, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, 0, B.partial.as<double>())) < 0)
+            rc = launch_autocov_first_b(nacc, grid, ls, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, 0, B.partial.as<double>());
+        timing_end(ls);
+        if (rc < 0) return set_error(MCMCHIP_EINVAL, "initseq: no kernel for %d accumulators", nacc);
+        if (rc) return rc;
+        HIP_TRY(hipGetLastError());
+    }
+    if (overlap)
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventRecord(dc->join_ev[i], dc->side[i]));
+            HIP_TRY(hipStreamWaitEvent(s, dc->join_ev[i], 0));
+        }
+    const long total = (long)nunit * IS_B;
+    static_assert(IS_B == 16, "autocov_reduce_kernel splits 256 threads into 16 parts x 16 lags");
+    hipLaunchKernelGGL(autocov_reduce_kernel, dim3((unsigned)nunit), dim3(256), 0, s, B.partial.as<double>(), nblk_run,
+                       B.sums.as<double>());
+    HIP_TRY(hipGetLastError());
+    host.resize((size_t)total);
+    HIP_TRY(hipMemcpyAsync(host.data(), B.sums.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return MCMCHIP_OK;
+}
+
+// Where will the stop rule fire?  Gamma_k of a geometrically mixing chain decays like r^k and the rule (first
+// negative Gamma, initseq.c:42-46) fires once the sequence reaches its noise floor, about Gamma_0 / sqrt(len):
+// the decay is read off the part of the sequence that is still well above the noise (>= 10 % of Gamma_0) and
+// extrapolated.  Returns the expected number of lag PAIRS; only the amount of speculative work depends on it.
+double predict_pairs(const double *G, long m, long len)
+{
+    if (m < 2 || !(G[0] > 0.0)) return 1.0;
+    long j = 0;
+    while (j + 1 < m && G[j + 1] > 0.1 * G[0] && G[j + 1] < G[j]) j++;
+    if (j == 0) {
+        if (!(G[1] > 0.0) || !(G[1] < G[0])) return 2.0;
+        j = 1;
+    }
+    const double decay = std::log(G[0] / G[j]) / (double)j;        // per lag pair
+    return 0.5 * std::log((double)len) / decay;
+}
+}  // namespace
+
+#define IS_MAX_UNITS_PER_LAUNCH 64      // at most 1024 new lags per column and round
+#define IS_PILOT_POSITIONS (1L << 21)   // pilot pass: at most the first 2M positions of every column
+
+int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0, double *Gpos,
+                double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon, DeviceCtx *dc)
+{
+    const long half = len / 2;
+    // tiles start at position -16 (zero padded), so the 4 result rows of an MFMA see every base position
+    const TimeGrid tg(len);
+    const long nblk = tg.nblk;
+    if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
+    // The stopping lag is data dependent, so lags are produced speculatively in units of 16.  Long series start
+    // with a PILOT: 64 lags of every column over its first 2M positions only (~1 % of a pass), whose Gamma
+    // sequence predicts where the stop rule will fire; the first full pass then asks each column for that many
+    // lags plus a margin, so most columns need one pass over HBM.  A column that is still active afterwards gets
+    // 20 % more lags per further round.  The sums themselves do not depend on any of this.
+    const bool trace = getenv("MCMCHIP_TRACE") != nullptr;
+    LagBuffers bufs;
+    LagRound work;
+    std::vector<std::vector<double>> Gam((size_t)ncol);   // Gamma_i per column, as far as computed
+    std::vector<long> done((size_t)ncol, -1);            // output length once the stop rule fired
+    std::vector<long> have((size_t)ncol, 0);             // lags computed so far
+    std::vector<double> g0((size_t)ncol, 0.0);
+    std::vector<double> guess((size_t)ncol, 0.0);        // predicted lag pairs
+    std::vector<int> rounds((size_t)ncol, 0);            // full-length launches a column has taken part in
+    std::vector<int> active;
+    for (long c = 0; c < ncol; c++) active.push_back((int)c);
+    std::vector<double> host;
+    timing_reset("autocov_kernel");
+    if (half == 0) active.clear();
+    long npilot = 0;                                     // time blocks of the pilot: 1/64 of a series of 1M positions and more
+    if (len >= (1L << 20)) {
+        const long pos = len / 64 < IS_PILOT_POSITIONS ? len / 64 : IS_PILOT_POSITIONS;
+        npilot = (pos + tg.span - 1) / tg.span;
+    }
+    if (npilot > 0 && !active.empty()) {
+        work.clear();
+        for (int c : active) work.add(c, 0, 64 / IS_B);
+        if (int rc = run_lag_round(x, len, tg, npilot, work, bufs, host, dc)) return rc;
+        std::vector<double> G(32);
+        for (size_t a = 0; a < active.size(); a++) {
+            const double *g = host.data() + a * 64;
+            for (int j = 0; j < 32; j++) G[(size_t)j] = g[2 * j] + g[2 * j + 1];
+            guess[(size_t)active[a]] = predict_pairs(G.data(), 32, len);
+        }
+        if (trace) fprintf(stderr, "[initseq] pilot: %zu columns x 64 lags over %ld of %ld time blocks\n", active.size(), npilot, nblk);
+    }
+    while (!active.empty()) {
+        work.clear();
+        for (int c : active) {
+            const long h = have[(size_t)c];
+            long nb;
+            if (rounds[(size_t)c] == 0 && npilot == 0) {
+                nb = 64 / IS_B;                                      // no pilot: 64 full-length lags are the prediction
+            } else if (rounds[(size_t)c] == 0 || (rounds[(size_t)c] == 1 && npilot == 0)) {
+                // The first pass sized by the prediction.  Measured at C5 size the stop comes at 0.7 ... 2 x the
+                // prediction (median 1.18, upper decile 1.76: the rule fires in the noise).  A column of few lags is
+                // HBM-bound and a second pass over it costs as much as the first, so it gets a generous margin; a
+                // column of many lags is MFMA-bound, every extra lag costs, and a further round is cheap by comparison.
+                const double p = npilot > 0 ? guess[(size_t)c] : predict_pairs(Gam[(size_t)c].data(), (long)Gam[(size_t)c].size(), len);
+                const double f = p <= 16.0 ? 1.7 : (p <= 40.0 ? 1.4 : (p <= 150.0 ? 1.15 : 1.05));
+                const double want = 2.0 * p * f + 4.0 - (double)h;
+                nb = want > 0.0 ? (long)std::ceil(want / IS_B) : 1;
+            } else {
+                nb = (long)std::ceil((h <= 256 ? 0.4 : 0.2) * (double)h / IS_B);      // overshoot of the stop rule into the noise
+            }
+            if (nb < 1) nb = 1;
+            rounds[(size_t)c]++;
+            if (nb > IS_MAX_UNITS_PER_LAUNCH) nb = IS_MAX_UNITS_PER_LAUNCH;
+            const long need = (2 * half - h + IS_B - 1) / IS_B;    // never past lag 2*half
+            if (nb > need) nb = need;
+            work.add(c, h, nb);
+        }
+        const long nitem = (long)work.unit_col.size();         // units
+        if (trace)
+        {
+            fprintf(stderr, "[initseq] round: %zu active columns, %ld units of %d lags, %ld time blocks; items x lags:", active.size(), nitem, IS_B, nblk);
+            for (int k = 0; k < kNumVariants; k++)
+                if (!work.items[k].empty()) fprintf(stderr, " %zu x %d%s", work.items[k].size(), 16 * kVariants[k].nacc, kVariants[k].first ? "" : "c");
+            fprintf(stderr, "\n");
+        }
+        if (int rc = run_lag_round(x, len, tg, nblk, work, bufs, host, dc)) return rc;
+        const std::vector<int> &item_col_flat = work.unit_col;
+        std::vector<int> next;
+        long it = 0;
+        for (int c : active) {
+            long nb = 0;
+            while (it + nb < nitem && item_col_flat[(size_t)(it + nb)] == c) nb++;
+            const double *g = host.data() + (size_t)it * IS_B;    // lags have[c] .. have[c] + nb*16
+            const long lag_first = have[(size_t)c];
+            bool fin = false;
+            for (long q = 0; q < nb * IS_B / 2 && !fin; q++) {
+                const long i = lag_first / 2 + q;
+                if (i >= half) { done[(size_t)c] = half; fin = true; break; }
+                const double gam1 = g[2 * q] / len, gam2 = g[2 * q + 1] / len;    // initseq.c:30,39
+                if (i == 0) {
+                    g0[(size_t)c] = gam1;
+                    // the lag-0 sum of squares is finite iff every element is (short of overflow): this is where a
+                    // series handed over as a device pointer gets the reference's finiteness check (initseq.c:15)
+                    if (!std::isfinite(gam1)) {
+                        int bits = 0;
+                        if (int rc = device_validate(dc, x + (size_t)c * len, len, 1, 0, &bits)) return rc;
+                        if (bits) return set_error(MCMCHIP_EINVAL, "all elements of argument must be finite");
+                        return set_error(MCMCHIP_EDOMAIN, "initseq: the lag-0 sum of squares of column %ld overflows", (long)c);
+                    }
+                }
+                double G = gam1 + gam2;
+                if (G < 0.0) {                                                    // initseq.c:42-46
+                    Gam[(size_t)c].push_back(0.0);
+                    done[(size_t)c] = i + 1;
+                    fin = true;
+                } else {
+                    Gam[(size_t)c].push_back(G);
+                    if (i + 1 >= half) { done[(size_t)c] = half; fin = true; }
+                }
+            }
+            have[(size_t)c] += nb * IS_B;
+            it += nb;
+            if (!fin) next.push_back(c);
+            else if (trace && getenv("MCMCHIP_TRACE")[0] == '2')
+                fprintf(stderr, "[initseq] column %d: predicted %.1f pairs, stopped at %ld, computed %ld lags in %d rounds\n",
+                        c, guess[(size_t)c], done[(size_t)c], have[(size_t)c], rounds[(size_t)c]);
+        }
+        active.swap(next);
+    }
+    bool overflow = false;
+    for (long c = 0; c < ncol; c++) {
+        long m = half == 0 ? 0 : done[(size_t)c];
+        n_out[c] = m;
+        gamma0[c] = g0[(size_t)c];
+        if (m > cap) { overflow = true; continue; }
+        gamma_sequences(Gam[(size_t)c].data(), m, g0[(size_t)c],
+                        GammaOut{Gpos + (size_t)c * cap, Gdec + (size_t)c * cap, Gcon + (size_t)c * cap, vpos + c, vdec + c, vcon + c});
+    }
+    if (overflow) return set_error(MCMCHIP_ECAP, "initseq: output capacity too small; required lengths are in n_out");
+    return MCMCHIP_OK;
+}
+
+// raw lag sums sum_t x[t] x[t + l], l = 0 .. nlags-1, of every column over the whole array given (zero beyond its end):
+// what a time-sharded initseq all-reduces (mcmc_amd/dist.py::initseq_time_sharded)
+int run_lagsums(const double *x, long len, long ncol, long nlags, double *sums, DeviceCtx *dc)
+{
+    const TimeGrid tg(len);
+    const long nblk = tg.nblk;
+    if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
+    const long units = (nlags + IS_B - 1) / IS_B;
+    LagBuffers bufs;
+    LagRound work;
+    std::vector<long> first((size_t)ncol);
+    for (long c = 0; c < ncol; c++) {
+        first[(size_t)c] = (long)work.unit_col.size();
+        work.add((int)c, 0, units);
+    }
+    std::vector<double> host;
+    timing_reset("autocov_kernel");
+    if (int rc = run_lag_round(x, len, tg, nblk, work, bufs, host, dc)) return rc;
+    for (long c = 0; c < ncol; c++)
+        for (long l = 0; l < nlags; l++) sums[(size_t)c * nlags + l] = host[(size_t)first[(size_t)c] * IS_B + l];
+    return MCMCHIP_OK;
+}
+
+// the stop rule and the three sequences from TOTAL lag sums (host only; initseq.c:24-105 on sums computed elsewhere).
+// n_out[c] = -1 when column c has not reached its stopping lag within nlags: the caller comes back with more lags.
+int run_initseq_from_lagsums(const double *sums, long len, long ncol, long nlags, long cap, long *n_out, double *gamma0,
+                             double *Gpos, double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon)
+{
+    const long half = len / 2;
+    bool overflow = false;
+    std::vector<double> G;
+    for (long c = 0; c < ncol; c++) {
+        const double *g = sums + (size_t)c * nlags;
+        G.clear();
+        long m = -1;
+        double g0 = 0.0;
+        if (half == 0) m = 0;
+        for (long i = 0; m < 0 && 2 * i + 1 < nlags; i++) {
+            if (i >= half) { m = half; break; }
+            const double gam1 = g[2 * i] / len, gam2 = g[2 * i + 1] / len;        // initseq.c:30,39
+            if (i == 0) g0 = gam1;
+            const double Gi = gam1 + gam2;
+            if (Gi < 0.0) { G.push_back(0.0); m = i + 1; }                        // initseq.c:42-46
+            else { G.push_back(Gi); if (i + 1 >= half) m = half; }
+        }
+        gamma0[c] = nlags > 0 ? g[0] / len : 0.0;
+        n_out[c] = m;
+        if (m < 0) continue;
+        if (m > cap) { overflow = true; continue; }
+        gamma_sequences(G.data(), m, g0, GammaOut{Gpos + (size_t)c * cap, Gdec + (size_t)c * cap, Gcon + (size_t)c * cap,
+                                                   vpos + c, vdec + c, vcon + c});
+    }
+    if (overflow) return set_error(MCMCHIP_ECAP, "initseq: output capacity too small; required lengths are in n_out");
+    return MCMCHIP_OK;
+}
+
