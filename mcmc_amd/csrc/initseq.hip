@@ -102,16 +102,17 @@ void gamma_sequences(const double *G, long m, double g0, const GammaOut &o)
 // into launches; partial sums per time block, the fixed-order reduction over the time blocks, and the sums back on
 // the host
 namespace {
-// instantiated kernels: items that start at lag 0 (initseq_first_a/b.hip; fine steps, because the unit count of an
-// item is rounded up to the next one and these carry > 90 % of the work: 33 units used to run as 48) and
-// continuation items (initseq_cont.hip)
-struct Variant { int nacc; bool first; };
+// instantiated kernels (a unit = 16 sums = 32 lags): lag pairs from lag 0 on (initseq_first_a/b.hip; fine steps,
+// because the unit count of an item is rounded up to the next one and these carry > 90 % of the work), lag pairs of
+// continuation items (initseq_cont.hip), single lags of one parity (initseq_raw.hip)
+enum Family { FAM_FIRST = 0, FAM_CONT = 1, FAM_RAW = 2 };
+struct Variant { int nacc; int fam; };
 const Variant kVariants[] = {
-    {1, true}, {2, true}, {3, true}, {4, true}, {5, true}, {6, true}, {7, true}, {8, true}, {9, true}, {10, true},
-    {11, true}, {12, true}, {13, true}, {14, true}, {16, true}, {18, true}, {20, true}, {22, true}, {24, true},
-    {28, true}, {32, true}, {36, true}, {40, true}, {44, true}, {48, true},
-    {1, false}, {2, false}, {3, false}, {4, false}, {6, false}, {8, false}, {12, false}, {16, false}, {24, false},
-    {32, false}};
+    {1, FAM_FIRST}, {2, FAM_FIRST}, {3, FAM_FIRST}, {4, FAM_FIRST}, {5, FAM_FIRST}, {6, FAM_FIRST}, {7, FAM_FIRST},
+    {8, FAM_FIRST}, {9, FAM_FIRST}, {10, FAM_FIRST}, {11, FAM_FIRST}, {12, FAM_FIRST}, {14, FAM_FIRST}, {16, FAM_FIRST},
+    {18, FAM_FIRST}, {20, FAM_FIRST}, {22, FAM_FIRST}, {24, FAM_FIRST},
+    {2, FAM_CONT}, {3, FAM_CONT}, {4, FAM_CONT}, {6, FAM_CONT}, {8, FAM_CONT}, {12, FAM_CONT}, {16, FAM_CONT},
+    {1, FAM_RAW}, {2, FAM_RAW}, {4, FAM_RAW}, {8, FAM_RAW}, {16, FAM_RAW}, {24, FAM_RAW}};
 const int kNumVariants = (int)(sizeof kVariants / sizeof kVariants[0]);
 
 // time blocks: a workgroup walks `tpb` tiles of IS_TILE positions; a function of the length of the series alone, so
@@ -120,43 +121,59 @@ struct TimeGrid {
     long tpb, nblk, span;
     explicit TimeGrid(long len)
     {
-        const long ntiles = (len + 16 + IS_TILE - 1) / IS_TILE;
+        const long ntiles = (len + IS_PAD + IS_TILE - 1) / IS_TILE;
         tpb = ntiles / 256;
         if (tpb < 1) tpb = 1;
         if (tpb > 64) tpb = 64;
         span = tpb * IS_TILE;
-        nblk = (len + 16 + span - 1) / span;
+        nblk = (len + IS_PAD + span - 1) / span;
     }
 };
 
 struct LagRound {
     struct Item { int col, unit; long lag; };
-    std::vector<int> unit_col;                                  // per 16-lag unit, in (column, lag) order
+    long nunit = 0;                                              // units (16 sums each) of the round, in order of request
     std::vector<Item> items[kNumVariants];
     void clear()
     {
-        unit_col.clear();
+        nunit = 0;
         for (int w = 0; w < kNumVariants; w++) items[w].clear();
     }
-    // at least nb units (16 lags each) of column c from lag0 on: one item of the next instantiated size of its
-    // family, or several beyond IS_MAXACC.  Returns the units actually scheduled.
-    long add(int c, long lag0, long nb)
+    // at least nb units of column c from lag0 on: one item of the next instantiated size of its family, or several
+    // beyond the family's largest.  pairs: units of 16 Gamma sums (lags lag0 + 2e, + 2e + 1), and the item that starts
+    // at lag 0 is followed by one more unit whose first entry is the sum of squares (gamma_0); else units of 16 single
+    // lags lag0 + 2e.  Returns the first unit; *got = the data units scheduled (consecutive from there on, the sum of
+    // squares after the first item's).
+    long add(int c, long lag0, long nb, bool pairs, long *got, long *ssq_unit = nullptr)
     {
+        const long first_unit = nunit;
         long done = 0;
+        if (ssq_unit) *ssq_unit = -1;
         while (done < nb) {
-            const long rest = nb - done, lag = lag0 + done * IS_B;
-            const bool first = lag == 0;
+            const long rest = nb - done, lag = lag0 + done * IS_UNIT_LAGS;
+            const int fam = !pairs ? FAM_RAW : (lag == 0 ? FAM_FIRST : FAM_CONT);
             int w = -1;                                     // the family's first size that covers the rest, else its largest
             for (int v = 0; v < kNumVariants; v++)
-                if (kVariants[v].first == first) {
+                if (kVariants[v].fam == fam) {
                     w = v;
                     if (kVariants[v].nacc >= rest) break;
                 }
-            items[w].push_back(Item{c, (int)unit_col.size(), lag});
-            for (int u = 0; u < kVariants[w].nacc; u++) unit_col.push_back(c);
+            items[w].push_back(Item{c, (int)nunit, lag});
+            nunit += kVariants[w].nacc;
             done += kVariants[w].nacc;
+            if (fam == FAM_FIRST) {
+                // the sum-of-squares unit sits right behind the item's data units: the units of a column stay
+                // consecutive only if this item is the column's last of the round
+                if (ssq_unit) *ssq_unit = nunit;
+                nunit += 1;
+                if (done < nb) {                            // more than 768 lags at once from lag 0: keep the data units apart
+                    *got = done;
+                    return first_unit;
+                }
+            }
         }
-        return done;
+        *got = done;
+        return first_unit;
     }
 };
 
@@ -166,12 +183,12 @@ struct LagBuffers {
     std::vector<char> host_lists;
 };
 
-// runs the round over time blocks [0, nblk_run) and leaves unit_col.size() * IS_B sums in `host`
+// runs the round over time blocks [0, nblk_run) and leaves nunit * IS_B sums in `host`
 int run_lag_round(const double *x, long len, const TimeGrid &tg, long nblk_run, const LagRound &w, LagBuffers &B,
                   std::vector<double> &host, DeviceCtx *dc)
 {
     hipStream_t s = dc->stream;
-    const size_t nunit = w.unit_col.size();
+    const size_t nunit = (size_t)w.nunit;
     if (nunit > B.cap_units || (size_t)nblk_run > B.cap_blocks) {       // sizes follow the work list
         B.partial.release(); B.sums.release(); B.lists.release();
         B.cap_units = nunit > B.cap_units ? nunit : B.cap_units;
@@ -195,20 +212,13 @@ int run_lag_round(const double *x, long len, const TimeGrid &tg, long nblk_run, 
     if (nitem) HIP_TRY(hipMemcpyAsync(B.lists.p, B.host_lists.data(), nitem * 16, hipMemcpyHostToDevice, s));
     const long *dl = B.lists.as<long>();
     const int *dcol = (const int *)(dl + nitem), *dunit = dcol + nitem;
-    // the launches, long items first.  MCMCHIP_INITSEQ_OVERLAP=1 puts the MFMA-bound and the HBM-bound ones on two
-    // side streams (measured at full C5 size in round 2: no gain, span 117.7 ms vs 111 ms serial; off by default)
-    const bool overlap = getenv("MCMCHIP_INITSEQ_OVERLAP") != nullptr;
-    const int overlap_mode = overlap ? atoi(getenv("MCMCHIP_INITSEQ_OVERLAP")) : 0;
-    if (overlap) {
-        HIP_TRY(hipEventRecord(dc->fork_ev, s));
-        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(dc->side[i], dc->fork_ev, 0));
-    }
+    // the launches, short items first.  Side by side on two streams (short, HBM-heavy items next to long ones) they
+    // take the same time as one after the other, measured twice at full C5 size (round 2: span 117.7 ms vs 111 ms;
+    // round 3: 0.1026 s either way): the launches are bound by power, not by idle units (see initseq_kernels.h)
     int order[kNumVariants];
     for (int v = 0; v < kNumVariants; v++) order[v] = v;
-    const bool descending = getenv("MCMCHIP_INITSEQ_DESCENDING") != nullptr;
     for (int i = 1; i < kNumVariants; i++)                                 // by accumulator count
-        for (int j = i; j > 0 && (descending ? kVariants[order[j]].nacc > kVariants[order[j - 1]].nacc
-                                             : kVariants[order[j]].nacc < kVariants[order[j - 1]].nacc); j--) {
+        for (int j = i; j > 0 && kVariants[order[j]].nacc < kVariants[order[j - 1]].nacc; j--) {
             const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp;
         }
     for (int o = 0; o < kNumVariants; o++) {
@@ -216,37 +226,34 @@ int run_lag_round(const double *x, long len, const TimeGrid &tg, long nblk_run, 
         const size_t ni = w.items[v].size();
         if (!ni) continue;
         const int nacc = kVariants[v].nacc;
-        hipStream_t ls = !overlap ? s : (overlap_mode == 2 ? dc->side[o & 1] : dc->side[nacc >= 5 ? 0 : 1]);
         dim3 grid((unsigned)ni, (unsigned)nblk_run);
-        long img = 0;
-        if (!kVariants[v].first)
-            for (const LagRound::Item &it : w.items[v]) {
-                const long need = autocov_cont_image(nacc, it.lag);
-                if (need > img) img = need;
-            }
         int rc;
-        timing_begin(ls);
-        if (!kVariants[v].first)
-            rc = launch_autocov_cont(nacc, grid, ls, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, (int)img, B.partial.as<double>());
-        else if ((rc = launch_autocov_first_a(nacc, grid, ls, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, 0, B.partial.as<double>())) < 0)
-            rc = launch_autocov_first_b(nacc, grid, ls, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, 0, B.partial.as<double>());
-        timing_end(ls);
+        timing_begin(s);
+        switch (kVariants[v].fam) {
+        case FAM_FIRST:
+            rc = launch_autocov_first_a(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
+            if (rc < 0) rc = launch_autocov_first_b(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
+            break;
+        case FAM_CONT:
+            rc = launch_autocov_cont(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
+            break;
+        default:
+            rc = launch_autocov_raw(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
+        }
+        timing_end(s);
         if (rc < 0) return set_error(MCMCHIP_EINVAL, "initseq: no kernel for %d accumulators", nacc);
         if (rc) return rc;
         HIP_TRY(hipGetLastError());
     }
-    if (overlap)
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipEventRecord(dc->join_ev[i], dc->side[i]));
-            HIP_TRY(hipStreamWaitEvent(s, dc->join_ev[i], 0));
-        }
     const long total = (long)nunit * IS_B;
     static_assert(IS_B == 16, "autocov_reduce_kernel splits 256 threads into 16 parts x 16 lags");
-    hipLaunchKernelGGL(autocov_reduce_kernel, dim3((unsigned)nunit), dim3(256), 0, s, B.partial.as<double>(), nblk_run,
-                       B.sums.as<double>());
-    HIP_TRY(hipGetLastError());
+    if (nunit) {
+        hipLaunchKernelGGL(autocov_reduce_kernel, dim3((unsigned)nunit), dim3(256), 0, s, B.partial.as<double>(), nblk_run,
+                           B.sums.as<double>());
+        HIP_TRY(hipGetLastError());
+    }
     host.resize((size_t)total);
-    HIP_TRY(hipMemcpyAsync(host.data(), B.sums.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    if (total) HIP_TRY(hipMemcpyAsync(host.data(), B.sums.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return MCMCHIP_OK;
 }
@@ -269,32 +276,34 @@ double predict_pairs(const double *G, long m, long len)
 }
 }  // namespace
 
-#define IS_MAX_UNITS_PER_LAUNCH 64      // at most 1024 new lags per column and round
+#define IS_MAX_UNITS_PER_LAUNCH 32      // at most 1024 new lags per column and round
 #define IS_PILOT_POSITIONS (1L << 21)   // pilot pass: at most the first 2M positions of every column
 
 int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0, double *Gpos,
                 double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon, DeviceCtx *dc)
 {
     const long half = len / 2;
-    // tiles start at position -16 (zero padded), so the 4 result rows of an MFMA see every base position
+    // tiles start at position -IS_PAD (zero padded), so every result row of an MFMA sees every base position
     const TimeGrid tg(len);
     const long nblk = tg.nblk;
     if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
-    // The stopping lag is data dependent, so lags are produced speculatively in units of 16.  Long series start
-    // with a PILOT: 64 lags of every column over its first 2M positions only (~1 % of a pass), whose Gamma
-    // sequence predicts where the stop rule will fire; the first full pass then asks each column for that many
-    // lags plus a margin, so most columns need one pass over HBM.  A column that is still active afterwards gets
-    // 20 % more lags per further round.  The sums themselves do not depend on any of this.
+    // The stopping lag is data dependent, so Gamma's are produced speculatively in units of 16 (32 lags).  Long series
+    // start with a PILOT: 32 Gamma's of every column over its first 2M positions only (~1 % of a pass), whose sequence
+    // predicts where the stop rule will fire; the first full pass then asks each column for that many plus a margin,
+    // so most columns need one pass over HBM.  A column that is still active afterwards gets 20-40 % more per further
+    // round.  The sums themselves do not depend on any of this.
     const bool trace = getenv("MCMCHIP_TRACE") != nullptr;
+    const int PU = IS_B;                                 // Gamma's (lag pairs) per unit
     LagBuffers bufs;
     LagRound work;
     std::vector<std::vector<double>> Gam((size_t)ncol);   // Gamma_i per column, as far as computed
     std::vector<long> done((size_t)ncol, -1);            // output length once the stop rule fired
-    std::vector<long> have((size_t)ncol, 0);             // lags computed so far
+    std::vector<long> have((size_t)ncol, 0);             // lag pairs computed so far
     std::vector<double> g0((size_t)ncol, 0.0);
     std::vector<double> guess((size_t)ncol, 0.0);        // predicted lag pairs
     std::vector<int> rounds((size_t)ncol, 0);            // full-length launches a column has taken part in
     std::vector<int> active;
+    std::vector<long> unit0, units, ssq_at;              // per active column of the round
     for (long c = 0; c < ncol; c++) active.push_back((int)c);
     std::vector<double> host;
     timing_reset("autocov_kernel");
@@ -306,23 +315,27 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
     }
     if (npilot > 0 && !active.empty()) {
         work.clear();
-        for (int c : active) work.add(c, 0, 64 / IS_B);
-        if (int rc = run_lag_round(x, len, tg, npilot, work, bufs, host, dc)) return rc;
-        std::vector<double> G(32);
+        unit0.assign(active.size(), 0);
         for (size_t a = 0; a < active.size(); a++) {
-            const double *g = host.data() + a * 64;
-            for (int j = 0; j < 32; j++) G[(size_t)j] = g[2 * j] + g[2 * j + 1];
-            guess[(size_t)active[a]] = predict_pairs(G.data(), 32, len);
+            long got;
+            unit0[a] = work.add(active[a], 0, 2, true, &got);
         }
+        if (int rc = run_lag_round(x, len, tg, npilot, work, bufs, host, dc)) return rc;
+        for (size_t a = 0; a < active.size(); a++)
+            guess[(size_t)active[a]] = predict_pairs(host.data() + (size_t)unit0[a] * IS_B, 2 * PU, len);
         if (trace) fprintf(stderr, "[initseq] pilot: %zu columns x 64 lags over %ld of %ld time blocks\n", active.size(), npilot, nblk);
     }
     while (!active.empty()) {
         work.clear();
-        for (int c : active) {
-            const long h = have[(size_t)c];
+        unit0.assign(active.size(), 0);
+        units.assign(active.size(), 0);
+        ssq_at.assign(active.size(), -1);
+        for (size_t a = 0; a < active.size(); a++) {
+            const int c = active[a];
+            const long h = have[(size_t)c];              // pairs so far
             long nb;
             if (rounds[(size_t)c] == 0 && npilot == 0) {
-                nb = 64 / IS_B;                                      // no pilot: 64 full-length lags are the prediction
+                nb = 2;                                              // no pilot: 64 full-length lags are the prediction
             } else if (rounds[(size_t)c] == 0 || (rounds[(size_t)c] == 1 && npilot == 0)) {
                 // The first pass sized by the prediction.  Measured at C5 size the stop comes at 0.7 ... 2 x the
                 // prediction (median 1.18, upper decile 1.76: the rule fires in the noise).  A column of few lags is
@@ -330,52 +343,49 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
                 // column of many lags is MFMA-bound, every extra lag costs, and a further round is cheap by comparison.
                 const double p = npilot > 0 ? guess[(size_t)c] : predict_pairs(Gam[(size_t)c].data(), (long)Gam[(size_t)c].size(), len);
                 const double f = p <= 16.0 ? 1.7 : (p <= 40.0 ? 1.4 : (p <= 150.0 ? 1.15 : 1.05));
-                const double want = 2.0 * p * f + 4.0 - (double)h;
-                nb = want > 0.0 ? (long)std::ceil(want / IS_B) : 1;
+                const double want = p * f + 2.0 - (double)h;
+                nb = want > 0.0 ? (long)std::ceil(want / PU) : 1;
             } else {
-                nb = (long)std::ceil((h <= 256 ? 0.4 : 0.2) * (double)h / IS_B);      // overshoot of the stop rule into the noise
+                nb = (long)std::ceil((h <= 128 ? 0.4 : 0.2) * (double)h / PU);      // overshoot of the stop rule into the noise
             }
             if (nb < 1) nb = 1;
             rounds[(size_t)c]++;
             if (nb > IS_MAX_UNITS_PER_LAUNCH) nb = IS_MAX_UNITS_PER_LAUNCH;
-            const long need = (2 * half - h + IS_B - 1) / IS_B;    // never past lag 2*half
+            const long need = (half - h + PU - 1) / PU;            // never past pair half - 1
             if (nb > need) nb = need;
-            work.add(c, h, nb);
+            unit0[a] = work.add(c, 2 * h, nb, true, &units[a], &ssq_at[a]);
         }
-        const long nitem = (long)work.unit_col.size();         // units
         if (trace)
         {
-            fprintf(stderr, "[initseq] round: %zu active columns, %ld units of %d lags, %ld time blocks; items x lags:", active.size(), nitem, IS_B, nblk);
+            fprintf(stderr, "[initseq] round: %zu active columns, %ld units of %d lags, %ld time blocks; items x lags:", active.size(), work.nunit, IS_UNIT_LAGS, nblk);
             for (int k = 0; k < kNumVariants; k++)
-                if (!work.items[k].empty()) fprintf(stderr, " %zu x %d%s", work.items[k].size(), 16 * kVariants[k].nacc, kVariants[k].first ? "" : "c");
+                if (!work.items[k].empty()) fprintf(stderr, " %zu x %d%s", work.items[k].size(), IS_UNIT_LAGS * kVariants[k].nacc, kVariants[k].fam == FAM_FIRST ? "" : "c");
             fprintf(stderr, "\n");
         }
         if (int rc = run_lag_round(x, len, tg, nblk, work, bufs, host, dc)) return rc;
-        const std::vector<int> &item_col_flat = work.unit_col;
         std::vector<int> next;
-        long it = 0;
-        for (int c : active) {
-            long nb = 0;
-            while (it + nb < nitem && item_col_flat[(size_t)(it + nb)] == c) nb++;
-            const double *g = host.data() + (size_t)it * IS_B;    // lags have[c] .. have[c] + nb*16
-            const long lag_first = have[(size_t)c];
+        for (size_t a = 0; a < active.size(); a++) {
+            const int c = active[a];
+            const long nb = units[a];
+            const double *g = host.data() + (size_t)unit0[a] * IS_B;    // pairs have[c] .. have[c] + nb*16
+            const long pair_first = have[(size_t)c];
             bool fin = false;
-            for (long q = 0; q < nb * IS_B / 2 && !fin; q++) {
-                const long i = lag_first / 2 + q;
-                if (i >= half) { done[(size_t)c] = half; fin = true; break; }
-                const double gam1 = g[2 * q] / len, gam2 = g[2 * q + 1] / len;    // initseq.c:30,39
-                if (i == 0) {
-                    g0[(size_t)c] = gam1;
-                    // the lag-0 sum of squares is finite iff every element is (short of overflow): this is where a
-                    // series handed over as a device pointer gets the reference's finiteness check (initseq.c:15)
-                    if (!std::isfinite(gam1)) {
-                        int bits = 0;
-                        if (int rc = device_validate(dc, x + (size_t)c * len, len, 1, 0, &bits)) return rc;
-                        if (bits) return set_error(MCMCHIP_EINVAL, "all elements of argument must be finite");
-                        return set_error(MCMCHIP_EDOMAIN, "initseq: the lag-0 sum of squares of column %ld overflows", (long)c);
-                    }
+            if (ssq_at[a] >= 0) {
+                const double gam0 = host[(size_t)ssq_at[a] * IS_B] / len;            // initseq.c:30 at lag 0
+                g0[(size_t)c] = gam0;
+                // the lag-0 sum of squares is finite iff every element is (short of overflow): this is where a
+                // series handed over as a device pointer gets the reference's finiteness check (initseq.c:15)
+                if (!std::isfinite(gam0)) {
+                    int bits = 0;
+                    if (int rc = device_validate(dc, x + (size_t)c * len, len, 1, 0, &bits)) return rc;
+                    if (bits) return set_error(MCMCHIP_EINVAL, "all elements of argument must be finite");
+                    return set_error(MCMCHIP_EDOMAIN, "initseq: the lag-0 sum of squares of column %ld overflows", (long)c);
                 }
-                double G = gam1 + gam2;
+            }
+            for (long q = 0; q < nb * PU && !fin; q++) {
+                const long i = pair_first + q;
+                if (i >= half) { done[(size_t)c] = half; fin = true; break; }
+                const double G = g[q] / len;                                          // gam1 + gam2, initseq.c:30,39,41
                 if (G < 0.0) {                                                    // initseq.c:42-46
                     Gam[(size_t)c].push_back(0.0);
                     done[(size_t)c] = i + 1;
@@ -385,12 +395,11 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
                     if (i + 1 >= half) { done[(size_t)c] = half; fin = true; }
                 }
             }
-            have[(size_t)c] += nb * IS_B;
-            it += nb;
+            have[(size_t)c] += nb * PU;
             if (!fin) next.push_back(c);
             else if (trace && getenv("MCMCHIP_TRACE")[0] == '2')
                 fprintf(stderr, "[initseq] column %d: predicted %.1f pairs, stopped at %ld, computed %ld lags in %d rounds\n",
-                        c, guess[(size_t)c], done[(size_t)c], have[(size_t)c], rounds[(size_t)c]);
+                        c, guess[(size_t)c], done[(size_t)c], 2 * have[(size_t)c], rounds[(size_t)c]);
         }
         active.swap(next);
     }
@@ -408,25 +417,28 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
 }
 
 // raw lag sums sum_t x[t] x[t + l], l = 0 .. nlags-1, of every column over the whole array given (zero beyond its end):
-// what a time-sharded initseq all-reduces (mcmc_amd/dist.py::initseq_time_sharded)
+// what a time-sharded initseq all-reduces (mcmc_amd/dist.py::initseq_time_sharded).  Single lags: the even and the odd
+// ones of a column are two work items (the kernel's units hold lags of one parity).
 int run_lagsums(const double *x, long len, long ncol, long nlags, double *sums, DeviceCtx *dc)
 {
     const TimeGrid tg(len);
     const long nblk = tg.nblk;
     if (nblk > 65535) return set_error(MCMCHIP_EINVAL, "initseq: series longer than 2^32 elements");
-    const long units = (nlags + IS_B - 1) / IS_B;
+    const long n_even = (nlags + 1) / 2, n_odd = nlags / 2;
     LagBuffers bufs;
     LagRound work;
-    std::vector<long> first((size_t)ncol);
+    std::vector<long> first_even((size_t)ncol, 0), first_odd((size_t)ncol, 0);
     for (long c = 0; c < ncol; c++) {
-        first[(size_t)c] = (long)work.unit_col.size();
-        work.add((int)c, 0, units);
+        long got;
+        if (n_even) first_even[(size_t)c] = work.add((int)c, 0, (n_even + IS_B - 1) / IS_B, false, &got);
+        if (n_odd) first_odd[(size_t)c] = work.add((int)c, 1, (n_odd + IS_B - 1) / IS_B, false, &got);
     }
     std::vector<double> host;
     timing_reset("autocov_kernel");
     if (int rc = run_lag_round(x, len, tg, nblk, work, bufs, host, dc)) return rc;
     for (long c = 0; c < ncol; c++)
-        for (long l = 0; l < nlags; l++) sums[(size_t)c * nlags + l] = host[(size_t)first[(size_t)c] * IS_B + l];
+        for (long l = 0; l < nlags; l++)
+            sums[(size_t)c * nlags + l] = host[(size_t)((l & 1) ? first_odd[(size_t)c] : first_even[(size_t)c]) * IS_B + l / 2];
     return MCMCHIP_OK;
 }
 

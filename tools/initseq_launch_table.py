@@ -20,8 +20,10 @@ print("%5s %5s %6s %9s %8s %8s %7s %7s" % ("NACC", "first", "items", "ms", "ms/i
       ("  %6s %6s %6s %6s" % ("GHz", "mfma%", "lds%", "wait%") if pmc else ""))
 tot = 0.0
 for r in rows:
-    m = re.search(r"autocov_kernel<(\d+), (\w+)>", r["Kernel_Name"])
+    m = re.search(r"autocov_kernel<(\d+), (\w+)(?:, (\w+))?>", r["Kernel_Name"])
     nacc, first = int(m.group(1)), m.group(2) == "true"
+    if m.group(3):
+        nacc *= 2                                   # round 3: an accumulator = 16 lag pairs = 32 lags
     ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
     items = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
     nblk = int(r["Grid_Size_Y"])
