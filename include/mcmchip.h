@@ -273,8 +273,9 @@ void mcmchip_target_destroy(mcmchip_target *t);
 int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchain, int path,
                     int device_ptrs, double *out);
 
-/* mcmchip_logdens_noalloc -- NO COUNTERPART IN THE REFERENCE.  For callers that cannot call hipMalloc: code under
- * HIP graph capture, tight serving loops, harnesses that forbid allocation.  The fp64 MFMA log density of
+/* mcmchip_logdens_noalloc -- NO COUNTERPART IN THE REFERENCE.  For callers that cannot call hipMalloc:
+ * tight serving loops, harnesses that forbid allocation (it launches on the library's own stream and waits for it, so
+ * it is NOT something to call under HIP graph capture).  The fp64 MFMA log density of
  * mcmchip_logdens(path = MFMA, device_ptrs = 1) with the same launch plan and therefore the same bits, but its
  * scratch (dimension-major states + per-split partial sums) lives in a fixed device array of
  * MCMCHIP_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends; the call makes no

@@ -426,8 +426,10 @@ def tune_pseudo_prior(x, y, models, initial, neighbors, nbatch, blen=1, nspac=1,
         qux <- qux + pmin(log(max(ibar) / ibar), 10);  qux <- qux - min(qux)        (bfst.Rnw:516-517, 546-547)
     with ibar = colMeans(ibatch), continuing from the last state (544), until max(ibar) / min(ibar) < 2 (550).
     `initial` is c(i, beta) or nens x (1 + d) (ibar then averages over the ensembles too).
-    Returns {"log.pseudo.prior", "qux.save", "ibar.save", "rounds", "out"}; the log 10 unnormalized Bayes factors of
-    bfst.Rnw:610 are (log.pseudo.prior - log(colMeans(out["ibatch"]))) / log(10)."""
+    As in the vignette the update comes before the test, so "log.pseudo.prior" is one update ahead of the last run;
+    "log.pseudo.prior.run" is what `out` was sampled with.
+    Returns {"log.pseudo.prior", "log.pseudo.prior.run", "qux.save", "ibar.save", "rounds", "out"}; the log 10
+    unnormalized Bayes factors of bfst.Rnw:610 are (log.pseudo.prior.run - log(colMeans(out["ibatch"]))) / log(10)."""
     models = np.asarray(models)
     k = models.shape[0]
     qux = np.zeros(k) if log_pseudo_prior is None else np.asarray(log_pseudo_prior, dtype=np.float64).copy()
@@ -446,14 +448,15 @@ def tune_pseudo_prior(x, y, models, initial, neighbors, nbatch, blen=1, nspac=1,
         ib = np.asarray(out["ibatch"])
         ibar = ib.reshape(-1, k).mean(axis=0)
         ibar_save.append(ibar)
-        if ibar.min() > 0 and ibar.max() / ibar.min() < ratio:
-            break
+        qux_run = qux                              # what this run sampled with: Bayes factors pair it with this ibar
         with np.errstate(divide="ignore"):
             qux = qux + np.minimum(np.log(ibar.max() / ibar), cap)
         qux = qux - qux.min()
         qux_save.append(qux.copy())
-    return {"log.pseudo.prior": qux, "qux.save": np.array(qux_save), "ibar.save": np.array(ibar_save),
-            "rounds": rounds, "out": out}
+        if ibar.min() > 0 and ibar.max() / ibar.min() < ratio:      # after the update, as bfst.Rnw:546-550 has it
+            break
+    return {"log.pseudo.prior": qux, "log.pseudo.prior.run": qux_run, "qux.save": np.array(qux_save),
+            "ibar.save": np.array(ibar_save), "rounds": rounds, "out": out}
 
 
 def initseq(x, centred=False):

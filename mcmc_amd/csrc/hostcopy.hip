@@ -83,7 +83,7 @@ hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipS
                 std::this_thread::yield();
             }
             // slices on 4 KiB boundaries: a page of the destination is first touched by one thread
-            const size_t len = chunk_len(c), per = ((len / T + 4095) / 4096) * 4096;
+            const size_t len = chunk_len(c), per = (((len + T - 1) / T + 4095) / 4096) * 4096;   // ceil(len / T): T * per >= len
             const size_t a = (size_t)t * per, b = a + per < len ? a + per : len;
             if (a < len) memcpy((char *)host + (size_t)c * HC_CHUNK + a, (const char *)g_ring.buf[c % HC_NBUF] + a, b - a);
             done[c].fetch_add(1, std::memory_order_release);
@@ -144,7 +144,7 @@ hipError_t copy_from_pageable_host(void *dev, const void *host, size_t bytes, hi
                 if (stop.load(std::memory_order_relaxed)) return;
                 std::this_thread::yield();
             }
-            const size_t len = chunk_len(c), per = ((len / T + 4095) / 4096) * 4096;
+            const size_t len = chunk_len(c), per = (((len + T - 1) / T + 4095) / 4096) * 4096;   // ceil(len / T): T * per >= len
             const size_t a = (size_t)t * per, b = a + per < len ? a + per : len;
             if (a < len) memcpy((char *)g_ring.buf[c % HC_NBUF] + a, (const char *)host + (size_t)c * HC_CHUNK + a, b - a);
             filled[c].fetch_add(1, std::memory_order_release);

@@ -810,19 +810,10 @@ static int temper_nout(const TemperDev &q)
     return q.parallel ? q.k * q.p : q.p;
 }
 
-// one launch of the chosen kernel over q.it_begin .. q.it_end
-static int launch_temper_once(const TemperDev &q, bool run_kernel, hipStream_t s, size_t *carry_doubles)
+// LDS layout of temper_kernel for this call (one place: the launch and the size of the carry record both use it)
+static TemperLds temper_lds_layout(const TemperDev &q)
 {
     const int k = q.k, p = q.p, maxnn = q.maxnn;
-    if (run_kernel) {
-        *carry_doubles = (size_t)64 * (2 * p + 3) + 2 * (size_t)k * maxnn;
-#define RUN_CASE(PP) \
-        case PP: return q.kind == MCMCHIP_T_WITCH ? launch_temper_run<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
-                                                  : launch_temper_run<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
-        switch (p) { RUN_CASE(1) RUN_CASE(2) RUN_CASE(3) RUN_CASE(4) }
-#undef RUN_CASE
-        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path: bad dimension %d", p);
-    }
     const int nstate = q.parallel ? k * p : p + 1;
     const int nout = temper_nout(q);
     TemperLds lay;
@@ -850,8 +841,31 @@ static int launch_temper_once(const TemperDev &q, bool run_kernel, hipStream_t s
     lay.par = o; o += lay.npar_lds;
     lay.scale = o; o += lay.nscale_lds;
     lay.end = o;
-    *carry_doubles = (size_t)lay.ubuf;
-    size_t bytes = (size_t)o * 8;
+    return lay;
+}
+
+// doubles of an ensemble's carry record between two launches: temper_run_kernel keeps the draws of a window and its
+// counters, temper_kernel its whole LDS record up to the random-number buffers
+static size_t temper_carry_doubles(const TemperDev &q, bool run_kernel)
+{
+    if (run_kernel) return (size_t)64 * (2 * q.p + 3) + 2 * (size_t)q.k * q.maxnn;
+    return (size_t)temper_lds_layout(q).ubuf;
+}
+
+// one launch of the chosen kernel over q.it_begin .. q.it_end
+static int launch_temper_once(const TemperDev &q, bool run_kernel, hipStream_t s)
+{
+    const int p = q.p, maxnn = q.maxnn;
+    if (run_kernel) {
+#define RUN_CASE(PP) \
+        case PP: return q.kind == MCMCHIP_T_WITCH ? launch_temper_run<PP, MCMCHIP_T_WITCH>(q, maxnn, s) \
+                                                  : launch_temper_run<PP, MCMCHIP_T_TEMPERED_NORMMIX>(q, maxnn, s);
+        switch (p) { RUN_CASE(1) RUN_CASE(2) RUN_CASE(3) RUN_CASE(4) }
+#undef RUN_CASE
+        return set_error(MCMCHIP_EINVAL, "run-parallel tempering path: bad dimension %d", p);
+    }
+    const TemperLds lay = temper_lds_layout(q);
+    size_t bytes = (size_t)lay.end * 8;
     if (bytes > 64 * 1024) return set_error(MCMCHIP_EINVAL, "tempering state (%zu bytes) does not fit the LDS budget", bytes);
     hipLaunchKernelGGL(temper_kernel, dim3((unsigned)q.nens), dim3(64), bytes, s, q, lay, maxnn);
     HIP_TRY(hipGetLastError());
@@ -889,22 +903,14 @@ int launch_temper(const TemperDev &q0, hipStream_t s)
         qq.it_begin = done;
         qq.it_end = done + n;
         qq.resume = done > 0;
-        size_t cd = 0;
         if (qq.it_end < niter && !carry.p) {
-            // size of an ensemble's carry record: ask the launcher (same formula it uses) without launching
-            cd = run_kernel ? (size_t)64 * (2 * p + 3) + 2 * (size_t)k * maxnn
-                            : (size_t)((q.parallel ? k * p : p + 1) + k + 2 * p +
-                                       temper_nout(q) + k +
-                                       2 * ((k + 1) / 2) + 3 * ((k * maxnn + 1) / 2) + (k + 1) / 2);
-            HIP_TRY(carry.alloc((size_t)q.nens * cd * 8));
+            HIP_TRY(carry.alloc((size_t)q.nens * temper_carry_doubles(q, run_kernel) * 8));
             qq.carry = carry.as<double>();
         }
-        size_t cd_used = 0;
         timing_begin(s);
-        int rc = launch_temper_once(qq, run_kernel, s, &cd_used);
+        int rc = launch_temper_once(qq, run_kernel, s);
         timing_end(s);
         if (rc) return rc;
-        if (cd && cd != cd_used) return set_error(MCMCHIP_EINVAL, "Can't happen: carry record size mismatch (%zu vs %zu)", cd, cd_used);
         done += n;
         if (done < niter) {
             last_ms = timing_last_ms();          // waits for the launch: the host poll point

@@ -220,7 +220,11 @@ def initseq_time_sharded(lagsums, finish, x_local, n, halo, group=None, device=N
     else:
         xc = x_local - mean
         tail = xc[own:]
-    nl = int(first_lags)
+    if ws > 1 and int(halo) < 2:
+        raise ValueError("initseq_time_sharded: the halo must hold at least 2 rows (one lag pair)")
+    # no round may ask for more lags than the halo serves: a rank's sums for lags beyond its halo would silently miss
+    # the terms whose partner row lies past its block
+    nl = min(int(first_lags), int(halo)) if ws > 1 else int(first_lags)
     while True:
         nl_eff = min(nl, int(n))
         part = np.asarray(lagsums(xc, nl_eff))

@@ -183,11 +183,12 @@ tune_pseudo_prior <- function(desc, initial, neighbors, nbatch, blen = 1, nspac 
         initial <- out$final
         ibar <- colMeans(out$ibatch)
         ibar.save <- rbind(ibar.save, ibar, deparse.level = 0)
-        if (max(ibar) / min(ibar) < ratio) break
+        qux.run <- qux
         qux <- qux + pmin(log(max(ibar) / ibar), cap)
         qux <- qux - min(qux)
         qux.save <- rbind(qux.save, qux, deparse.level = 0)
+        if (max(ibar) / min(ibar) < ratio) break      # after the update, as vignettes/bfst.Rnw:546-550
     }
-    list(log.pseudo.prior = qux, qux.save = qux.save, ibar.save = ibar.save, out = out,
+    list(log.pseudo.prior = qux, log.pseudo.prior.run = qux.run, qux.save = qux.save, ibar.save = ibar.save, out = out,
         descriptor = with_pseudo_prior(desc, qux))
 }

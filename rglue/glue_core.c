@@ -300,6 +300,9 @@ int glue_metrop_outfun(int type, const int *lgl, const double *num, int len, int
             const double v = num[i];
             if (isnan(v)) return fail(err, errlen, "NA or NaN index for outfun");
             if (!isfinite(v)) return fail(err, errlen, "-Inf or Inf index for outfun");
+            /* beyond int the reference's `int fooint = foodble` (metrop.c:457) is undefined; on x86-64 it yields INT_MIN
+               and the run ends in the not-an-integer error below: say so without the undefined conversion */
+            if (fabs(v) >= 2147483648.0) return fail(err, errlen, "is.numeric(outfun) & any(outfun != as.integer(outfun))");
             const int iv = (int)v;
             const int av = iv >= 0 ? iv : -iv;
             if (iv == 0) return fail(err, errlen, "is.numeric(outfun) & any(outfun == 0)");

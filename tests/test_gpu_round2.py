@@ -139,17 +139,25 @@ def test_device_pointer_inputs_are_validated(api):
     assert rc == abi.EINVAL and b"all elements of argument must be finite" in L.mcmchip_last_error()
 
 
-def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api, monkeypatch):
+@pytest.mark.parametrize("Cn,nbatch,thread_counts", [
+    (4099, 523, (None, "1", "0")),        # 85.75 MB of batch means: 5 whole 16 MB chunks and a ragged one
+    # the last chunk is 16 * 4096 * 242 + 8 bytes: with 16 copy threads floor(len / T) is a whole number of pages and
+    # T slices of that size stop 8 bytes short of the chunk (the last double was never copied before the slice size
+    # became ceil(len / T))
+    (4191, 595, ("16", "12", "32")),
+])
+def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api, monkeypatch, Cn, nbatch, thread_counts):
     """Results of 64 MB and more go back to pageable host memory through hostcopy.hip (pinned ring + host threads).
     The same Philox run with device_ptrs = 1 leaves them in HBM: both must hold the same bits, also when the last chunk
-    is ragged, with one copy thread, and with the plain copy (MCMCHIP_COPY_THREADS = 0)."""
+    is ragged, with one copy thread, with more threads than the default 8, and with the plain copy
+    (MCMCHIP_COPY_THREADS = 0)."""
     import ctypes as C
     import torch
     L = api.load_library()
     dev = torch.device("cuda", 0)
     X, y = load_logit()
     tg = api.logistic_target(X, y)
-    Cn, d, nbatch = 4099, 5, 523                      # 85.75 MB of batch means: 5 whole 16 MB chunks and a ragged one
+    d = 5
     rng = np.random.default_rng(3)
     init_h = 0.1 * rng.standard_normal((Cn, d))
     scale = np.array([0.4])
@@ -162,7 +170,7 @@ def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api
     assert L.mcmchip_metrop(tg.handle, C.addressof(args), C.addressof(out)) == 0, L.mcmchip_last_error()
     want = [t.cpu().numpy() for t in outs_d]
     assert want[1].nbytes >= 64 << 20
-    for threads in (None, "1", "0"):
+    for threads in thread_counts:
         if threads is None:
             monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
         else:
@@ -709,7 +717,8 @@ def test_tune_pseudo_prior_flattens_occupancy(api):
     assert ibar1.min() > 0 and ibar1.max() / ibar1.min() < 2.0
     assert res["log.pseudo.prior"].min() == 0.0
     # Bayes factors (bfst.Rnw:610): stable under a longer run at the tuned pseudo-prior
-    qux = res["log.pseudo.prior"]
+    qux = res["log.pseudo.prior.run"]              # what the last run sampled with ("log.pseudo.prior" is one update on)
+    assert np.array_equal(res["log.pseudo.prior"], res["qux.save"][-1]) and len(res["qux.save"]) == res["rounds"]
     bf1 = (qux - np.log(ibar1)) / np.log(10)
     tg = api.logistic_models_target(X, y, models, log_pseudo_prior=qux)
     o = api.temper(tg, res["out"]["final"], nb, 400, 50, 1, 0.5, parallel=False, seed=7)

@@ -204,12 +204,23 @@ for c in range(3):
     assert len(res[c]["Gamma.pos"]) == len(ref["Gamma.pos"]), c
     for key in ("gamma0", "Gamma.pos", "Gamma.dec", "Gamma.con", "var.pos", "var.dec", "var.con"):
         assert np.max(np.abs(np.asarray(res[c][key]) - np.asarray(ref[key]))) <= 1e-10 * np.max(np.abs(ref[key])), (c, key)
+# a halo below the default first round of 64 lags: the first round is clamped to the halo (sums for lags beyond it would
+# miss the terms whose partner row lies past the rank's block), so 48 rows serve these columns and give the same numbers
+lo48, hi48, _ = mdist.initseq_time_shard(raw.shape[0], 48, dist.get_rank(), 2)
+res48 = mdist.initseq_time_sharded(np_lagsums, api.initseq_from_lagsums, raw[lo48:hi48], raw.shape[0], 48)
+for c in range(3):
+    ref = oracle.initseq(raw[:, c] - raw[:, c].mean())
+    assert len(ref["Gamma.pos"]) * 2 <= 48, "the test wants stopping lags inside the halo"
+    assert len(res48[c]["Gamma.pos"]) == len(ref["Gamma.pos"]), c
+    assert abs(res48[c]["var.con"] - ref["var.con"]) <= 1e-10 * abs(ref["var.con"]), c
+# ... and a halo that cannot hold the stopping lag is an error, with the default first round as well
 lo8, hi8, _ = mdist.initseq_time_shard(raw.shape[0], 8, dist.get_rank(), 2)
-try:
-    mdist.initseq_time_sharded(np_lagsums, api.initseq_from_lagsums, raw[lo8:hi8], raw.shape[0], 8, first_lags=8)
-    raise SystemExit("a halo of 8 rows cannot hold the stopping lag of the rho = 0.9 column")
-except RuntimeError as e:
-    assert "beyond the halo" in str(e)
+for kw in ({"first_lags": 8}, {}):
+    try:
+        mdist.initseq_time_sharded(np_lagsums, api.initseq_from_lagsums, raw[lo8:hi8], raw.shape[0], 8, **kw)
+        raise SystemExit("a halo of 8 rows cannot hold the stopping lag of the rho = 0.9 column")
+    except RuntimeError as e:
+        assert "beyond the halo" in str(e)
 dist.destroy_process_group()
 print("ok")
 '''

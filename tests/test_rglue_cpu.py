@@ -135,6 +135,9 @@ def test_outfun_errors_are_the_references(G):
     assert num([6]) == (1, b"is.numeric(outfun) & any(abs(outfun) > length(initial)")
     assert num([1, -2]) == (1, b"is.numeric(outfun) & any(outfun > 0) & any(outfun < 0)")
     assert num([float("nan")]) == (1, b"NA or NaN index for outfun")
+    # beyond int: no undefined double -> int conversion, the error x86-64 R ends in (metrop.c:457-463)
+    assert num([1e10]) == (1, b"is.numeric(outfun) & any(outfun != as.integer(outfun))")
+    assert num([-3e9]) == (1, b"is.numeric(outfun) & any(outfun != as.integer(outfun))")
     assert num([float("inf")]) == (1, b"-Inf or Inf index for outfun")
     lg = np.ones(4, dtype=np.int32)
     assert G.glue_metrop_outfun(1, lg.ctypes.data, None, 4, d, C.byref(kind), mask.ctypes.data, C.byref(nout), e, 256) == 1
