@@ -331,6 +331,33 @@ int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean);
 int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
                  int32_t nocalc, int device_ptrs);
 
+/* Cross-chain diagnostics -- NO COUNTERPART IN THE REFERENCE, which runs one chain (its users read colMeans(out$batch)
+ * and apply(out$batch, 2, sd) / sqrt(out$nbatch), vignettes/demo.Rnw:210-222).  A batched call returns nchain x nbatch x
+ * nout batch means (mcmchip_metrop_out.batch); this reduces them over chains, per output functional j:
+ *   m_c = mean of chain c's batch means, s2_c = their variance (divisor nbatch - 1)
+ *   grand_mean = mean_c m_c;  between = sum_c (m_c - grand_mean)^2 / (nchain - 1);  within = mean_c s2_c
+ *   mcse_between = sqrt(between / nchain)           the chains as replicates
+ *   mcse_within  = sqrt(within / (nbatch nchain))   the batch-means estimate of demo.Rnw:218-222, pooled over chains
+ *   rhat = sqrt(((nbatch-1)/nbatch within + between) / within)   (potential scale reduction on the batch-mean scale)
+ *   mcse_initseq (optional, non-NULL asks for it) = sqrt(mean_c var.con_c / (nbatch nchain)), var.con_c from initseq
+ *     (R/initseq.R, initseq.c) on chain c's centred batch means: for a few long chains (nchain <= 65535,
+ *     nchain * nout * nbatch <= 2^28)
+ * Every output pointer may be NULL; the vectors are host memory, chain_mean / chain_var (nchain x nout) follow
+ * device_ptrs like `batch`.  stats (5 x nout doubles, host: count, mean, M2, sum of s2_c, sum of var.con_c per
+ * functional) are the sufficient statistics a sharded run exchanges: mcmchip_chain_summary_combine (host only) merges
+ * the stats of `nranks` shards IN RANK ORDER and fills the same vectors.  One chain: between / mcse_between / rhat are
+ * NaN (0/0); one batch: within is NaN. */
+typedef struct mcmchip_chain_summary_out {
+    double *grand_mean, *between, *within, *mcse_between, *mcse_within, *rhat;   /* nout each */
+    double *mcse_initseq;          /* nout, or NULL: skip the per-chain initseq */
+    double *stats;                 /* 5 x nout */
+    double *chain_mean, *chain_var; /* nchain x nout */
+} mcmchip_chain_summary_out;
+int mcmchip_chain_summary(const double *batch, int64_t nchain, int32_t nbatch, int32_t nout, int device_ptrs,
+                          mcmchip_chain_summary_out *out);
+int mcmchip_chain_summary_combine(const double *stats /* nranks x 5 x nout */, int32_t nranks, int32_t nbatch, int32_t nout,
+                                  mcmchip_chain_summary_out *out /* chain_mean, chain_var ignored; stats = the total */);
+
 /* Interrupts and launch length.  The reference calls R_CheckUserInterrupt() every iteration (metrop.c:269,
  * temper.c:848).  Here a sampler call is a sequence of kernel launches of about a quarter of a second each (one
  * short calibration launch first; the state is carried between launches, results are bit for bit those of a single

@@ -133,6 +133,12 @@ class TemperOut(C.Structure):
     ]
 
 
+class ChainSummaryOut(C.Structure):
+    """mcmchip_chain_summary_out (include/mcmchip.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("grand_mean", "between", "within", "mcse_between", "mcse_within", "rhat",
+                                          "mcse_initseq", "stats", "chain_mean", "chain_var")]
+
+
 # every symbol include/mcmchip.h declares (tests check the library exports them all)
 EXPORTS = [
     "mcmchip_init",
@@ -148,6 +154,8 @@ EXPORTS = [
     "mcmchip_lagsums",
     "mcmchip_initseq_from_lagsums",
     "mcmchip_olbm",
+    "mcmchip_chain_summary",
+    "mcmchip_chain_summary_combine",
     "mcmchip_series_upload",
     "mcmchip_series_free",
     "mcmchip_series_centre",

@@ -60,6 +60,10 @@ def load_library():
     L.mcmchip_temper.restype = C.c_int
     L.mcmchip_initseq.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64] + [C.c_void_p] * 8
     L.mcmchip_initseq.restype = C.c_int
+    L.mcmchip_chain_summary.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
+    L.mcmchip_chain_summary.restype = C.c_int
+    L.mcmchip_chain_summary_combine.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.mcmchip_chain_summary_combine.restype = C.c_int
     L.mcmchip_lagsums.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
     L.mcmchip_lagsums.restype = C.c_int
     L.mcmchip_initseq_from_lagsums.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 8
@@ -611,6 +615,70 @@ def initseq_from_lagsums(sums, length):
                    {"gamma0": g0[c], "Gamma.pos": Gp[c, :m].copy(), "Gamma.dec": Gd[c, :m].copy(),
                     "Gamma.con": Gc[c, :m].copy(), "var.pos": vp[c], "var.dec": vd[c], "var.con": vc[c]})
     return res
+
+
+_SUMMARY_VECTORS = ("grand_mean", "between", "within", "mcse_between", "mcse_within", "rhat")
+
+
+def _summary_struct(nout, want_initseq):
+    vec = {k: np.empty(nout) for k in _SUMMARY_VECTORS}
+    if want_initseq:
+        vec["mcse_initseq"] = np.empty(nout)
+    vec["stats"] = np.empty((5, nout))
+    o = abi.ChainSummaryOut()
+    for k, v in vec.items():
+        setattr(o, k, v.ctypes.data)
+    return o, vec
+
+
+def chain_summary(batch, initseq=False, per_chain=False):
+    """Cross-chain diagnostics of a batched run (mcmchip_chain_summary; no counterpart in the one-chain reference):
+    batch = out["batch"] of metrop, nchain x nbatch x nout (numpy, or a contiguous float64 CUDA tensor: nothing crosses
+    PCIe but 5 nout doubles).  Per output functional: "grand_mean", "between" (variance of the chain means), "within"
+    (mean variance of a chain's batch means), "mcse_between" = sqrt(between / nchain), "mcse_within" =
+    sqrt(within / (nbatch nchain)), "rhat"; initseq=True adds "mcse_initseq" (R/initseq.R on every chain's batch
+    means, var.con pooled); per_chain=True adds "chain_mean" and "chain_var" (nchain x nout).  "stats" (5 x nout) are
+    the sufficient statistics that chain_summary_combine / mcmc_amd.dist.chain_summary_sharded merge across ranks."""
+    init()
+    on_device = hasattr(batch, "data_ptr") and hasattr(batch, "is_cuda")
+    if on_device:
+        if not batch.is_cuda or batch.dim() != 3 or not batch.is_contiguous() or str(batch.dtype) != "torch.float64":
+            raise ValueError("a device batch must be a contiguous float64 CUDA tensor of shape (nchain, nbatch, nout)")
+        ptr, keep = batch.data_ptr(), batch
+    else:
+        keep = np.ascontiguousarray(batch, dtype=np.float64)
+        if keep.ndim == 2:
+            keep = keep[None]                      # one chain: the reference's nbatch x nout matrix
+        if keep.ndim != 3:
+            raise ValueError("batch must be nchain x nbatch x nout")
+        ptr = keep.ctypes.data
+    nchain, nbatch, nout = (int(v) for v in keep.shape)
+    o, vec = _summary_struct(nout, initseq)
+    if per_chain:
+        if on_device:
+            import torch
+            vec["chain_mean"] = torch.empty((nchain, nout), dtype=torch.float64, device=batch.device)
+            vec["chain_var"] = torch.empty((nchain, nout), dtype=torch.float64, device=batch.device)
+            o.chain_mean, o.chain_var = vec["chain_mean"].data_ptr(), vec["chain_var"].data_ptr()
+        else:
+            vec["chain_mean"], vec["chain_var"] = np.empty((nchain, nout)), np.empty((nchain, nout))
+            o.chain_mean, o.chain_var = vec["chain_mean"].ctypes.data, vec["chain_var"].ctypes.data
+    _check(load_library().mcmchip_chain_summary(ptr, nchain, nbatch, nout, int(on_device), C.addressof(o)))
+    vec.update(nchain=nchain, nbatch=nbatch)
+    return vec
+
+
+def chain_summary_combine(stats, nbatch):
+    """merge the "stats" (5 x nout each) of several shards IN THE ORDER GIVEN and return the summary of all their chains
+    (host only: mcmchip_chain_summary_combine)."""
+    st = np.ascontiguousarray(stats, dtype=np.float64)
+    if st.ndim != 3 or st.shape[1] != 5:
+        raise ValueError("stats must be nranks x 5 x nout")
+    nranks, _, nout = st.shape
+    o, vec = _summary_struct(nout, True)
+    _check(load_library().mcmchip_chain_summary_combine(st.ctypes.data, nranks, int(nbatch), nout, C.addressof(o)))
+    vec.update(nchain=int(round(vec["stats"][0, 0])), nbatch=int(nbatch))
+    return vec
 
 
 def olbm_device(x, batch_length, mean=None):

@@ -781,4 +781,43 @@ int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mea
     return run_olbm(in.as<double>(), n, p, len, mean, var, nocalc, dc);
 }
 
+// ---------------------------------------------------------------------------------------------
+int mcmchip_chain_summary(const double *batch, int64_t nchain, int32_t nbatch, int32_t nout, int device_ptrs,
+                          mcmchip_chain_summary_out *o)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!batch || !o || nchain <= 0 || nbatch <= 0 || nout <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_chain_summary");
+    const bool want_is = o->mcse_initseq != nullptr;
+    if (want_is && (nchain > 65535 || (double)nchain * nout * nbatch > (double)(1L << 28)))
+        return set_error(MCMCHIP_EINVAL, "mcse_initseq is for a few long chains: nchain <= 65535 and nchain * nout * nbatch <= 2^28");
+    hipStream_t s = dc->stream;
+    InBuf in;
+    HIP_TRY(in.set(batch, (size_t)nchain * nbatch * nout * 8, device_ptrs, s));
+    OutBuf cmean, cvar;
+    HIP_TRY(cmean.set(o->chain_mean, (size_t)nchain * nout * 8, device_ptrs));
+    HIP_TRY(cvar.set(o->chain_var, (size_t)nchain * nout * 8, device_ptrs));
+    std::vector<double> stats((size_t)5 * nout);
+    if (int rc = run_chain_summary(in.as<double>(), nchain, nbatch, nout, want_is, cmean.as<double>(), cvar.as<double>(), stats.data(), dc))
+        return rc;
+    HIP_TRY(cmean.finish(s));
+    HIP_TRY(cvar.finish(s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (o->stats) memcpy(o->stats, stats.data(), stats.size() * 8);
+    chain_summary_vectors(stats.data(), nbatch, nout, o, want_is);
+    return MCMCHIP_OK;
+}
+
+int mcmchip_chain_summary_combine(const double *stats, int32_t nranks, int32_t nbatch, int32_t nout, mcmchip_chain_summary_out *o)
+{
+    clear_error();                   // host only: no device is touched
+    if (!stats || !o || nranks <= 0 || nbatch <= 0 || nout <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_chain_summary_combine");
+    std::vector<double> total((size_t)5 * nout);
+    combine_chain_stats(stats, nranks, nout, total.data());
+    if (o->stats) memcpy(o->stats, total.data(), total.size() * 8);
+    chain_summary_vectors(total.data(), nbatch, nout, o, true);
+    return MCMCHIP_OK;
+}
+
 }  // extern "C"

@@ -103,3 +103,9 @@ int run_initseq_from_lagsums(const double *sums, long len, long ncol, long nlags
 int run_series_centre(double *x, long n, long p, double *mean, DeviceCtx *dc);
 int run_olbm(const double *x, long n, int p, long len, double *mean, double *var, int nocalc,
              DeviceCtx *dc);
+
+// summary.hip: cross-chain reduction of batch means; stats_host = 5 x nout sufficient statistics
+int run_chain_summary(const double *batch, long nchain, int nbatch, int nout, int want_initseq, double *chain_mean_out,
+                      double *chain_var_out, double *stats_host, DeviceCtx *dc);
+void combine_chain_stats(const double *stats, int nranks, int nout, double *total);
+void chain_summary_vectors(const double *stats, int nbatch, int nout, mcmchip_chain_summary_out *o, bool have_initseq);

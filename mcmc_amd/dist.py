@@ -184,6 +184,20 @@ def olbm_sharded(olbm_local, x_local, n, batch_length, group=None, device=None):
     return total / (float(nwin) * float(n) * float(batch_length)), mean
 
 
+def chain_summary_sharded(summary_local, combine, batch_local, group=None, device=None, **kw):
+    """Cross-chain diagnostics of a run sharded by chains (metrop row; north_star: RCCL "for the final
+    all-gather of batch means and cross-chain diagnostics"): every rank reduces ITS chains on its GPU
+    (summary_local = mcmc_amd.api.chain_summary: count, mean, M2, sum of within-chain variances, sum of var.con per
+    functional), one all-gather of those 5 nout doubles per rank, and every rank merges them in rank order
+    (combine = mcmc_amd.api.chain_summary_combine, host only): the same bits on every rank, whatever the collective's
+    internal order.  Returns the summary of ALL chains plus "local" (this rank's own)."""
+    local = summary_local(batch_local, **kw)
+    stats = all_gather_rows(np.asarray(local["stats"])[None], group, device)         # nranks x 5 x nout
+    out = combine(stats, local["nbatch"])
+    out["local"] = local
+    return out
+
+
 def initseq_time_shard(n, halo, rank, world_size):
     """rows [row_lo, row_hi) of the series that rank `rank` holds for a time-sharded initseq: its own block of base
     positions plus a halo of `halo` rows (the largest lag it can serve); returns (row_lo, row_hi, own)"""

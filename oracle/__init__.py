@@ -231,3 +231,25 @@ def olbm(x, batch_length, mean=None):
     if rc:
         raise OracleError(rc, "len > n\n")
     return var, m
+
+
+def chain_summary(batch, with_initseq=False):
+    """Cross-chain reduction of batch means (nchain x nbatch x nout), the definitions of include/mcmchip.h restated with
+    numpy (two-pass moments; the reference has no counterpart: its users do colMeans(out$batch) and
+    apply(out$batch, 2, sd) / sqrt(out$nbatch) for ONE chain, vignettes/demo.Rnw:210-222).  with_initseq: var.con of
+    orc_initseq (initseq.c) on every chain's centred batch means, pooled."""
+    b = np.asarray(batch, dtype=np.float64)
+    nchain, nbatch, nout = b.shape
+    m = b.mean(axis=1)                                   # nchain x nout
+    with np.errstate(invalid="ignore", divide="ignore"):
+        s2 = ((b - m[:, None, :]) ** 2).sum(axis=1) / (nbatch - 1)
+        gm = m.mean(axis=0)
+        between = ((m - gm) ** 2).sum(axis=0) / (nchain - 1)
+        within = s2.mean(axis=0)
+        out = {"grand_mean": gm, "between": between, "within": within, "mcse_between": np.sqrt(between / nchain),
+               "mcse_within": np.sqrt(within / (nbatch * nchain)),
+               "rhat": np.sqrt(((nbatch - 1) / nbatch * within + between) / within), "chain_mean": m, "chain_var": s2}
+    if with_initseq:
+        vc = np.array([[initseq(b[c, :, j] - m[c, j])["var.con"] for j in range(nout)] for c in range(nchain)])
+        out["mcse_initseq"] = np.sqrt(vc.mean(axis=0) / (nbatch * nchain))
+    return out

@@ -939,3 +939,74 @@ def test_bench_two_rank_strong_split_rehearsal():
     acc2, acc1 = r2["config"]["accept_rate"] * 65536 * 3, r1["config"]["accept_rate"] * 65536 * 3
     assert abs(acc2 - acc1) < 1e-6 and abs(acc1 - round(acc1)) < 1e-6
     assert r2["value"] > 0 and r2["roofline"]["frac"] > 0       # two ranks share one GPU here: no rate is asserted
+
+
+# ----------------------------------------------------------------------------- cross-chain diagnostics
+@pytest.mark.parametrize("nchain,nbatch,nout", [(4096, 10, 5), (333, 40, 64), (7, 25, 130), (1, 12, 3), (50, 1, 4),
+                                                (2, 2, 1), (70000, 3, 2)])
+def test_chain_summary_vs_oracle(api, oracle_mod, nchain, nbatch, nout):
+    """mcmchip_chain_summary against the numpy restatement of its definitions: batch means with a level far above their
+    spread (1 +- 1e-3: raw sums of squares would lose 6 digits, the pairwise moments must not), from host memory and
+    from HBM, per-chain outputs included; one chain / one batch give NaN where 0 / 0 says so."""
+    import torch
+    rng = np.random.default_rng(nchain * 131 + nbatch)
+    level = 1.0 + 0.2 * rng.standard_normal(nout)
+    chain_eff = 3e-4 * rng.standard_normal((nchain, 1, nout))
+    b = level + chain_eff + 1e-3 * rng.standard_normal((nchain, nbatch, nout))
+    ref = oracle_mod.chain_summary(b)
+    got_h = api.chain_summary(b, per_chain=True)
+    got_d = api.chain_summary(torch.from_numpy(b).to("cuda:0"), per_chain=True)
+    for got in (got_h, got_d):
+        assert got["nchain"] == nchain and got["nbatch"] == nbatch
+        for key in ("grand_mean", "between", "within", "mcse_between", "mcse_within", "rhat", "chain_mean", "chain_var"):
+            g = got[key].cpu().numpy() if hasattr(got[key], "cpu") else got[key]
+            r = ref[key]
+            assert np.array_equal(np.isnan(g), np.isnan(r)), key
+            ok = ~np.isnan(r)
+            # variances of a 3e-4 .. 1e-3 spread around 1: a chain mean is good to eps * level = 2e-16, so a variance of
+            # the means is conditioned to eps * level / spread ~ 1e-12 whoever computes it (the oracle's numpy means
+            # included); 1e-11 holds both sides to that, where raw sums of squares would sit at eps * (level / spread)^2 ~ 1e-9
+            tol = 1e-11 if key in ("between", "mcse_between", "rhat") else 1e-12
+            assert np.all(np.abs(g[ok] - r[ok]) <= tol * np.abs(r[ok]) + 1e-300), (key, np.max(np.abs(g[ok] - r[ok]) / np.abs(r[ok])))
+    for key in ("grand_mean", "between", "within", "stats"):
+        assert np.array_equal(got_h[key], got_d[key], equal_nan=True), key          # same kernel, same bits
+    # shards merged in rank order give the whole: ragged split into three
+    if nchain >= 3:
+        cuts = [0, nchain // 3, nchain // 3 + 1 + nchain // 2 if nchain > 5 else 2, nchain]
+        cuts = sorted(set(min(c, nchain) for c in cuts))
+        parts = [api.chain_summary(b[lo:hi])["stats"] for lo, hi in zip(cuts[:-1], cuts[1:])]
+        whole = api.chain_summary_combine(np.stack(parts), nbatch)
+        assert whole["nchain"] == nchain
+        for key in ("grand_mean", "between", "within", "mcse_between", "mcse_within", "rhat"):
+            r = ref[key]
+            ok = ~np.isnan(r)
+            assert np.all(np.abs(whole[key][ok] - r[ok]) <= 1e-11 * np.abs(r[ok]) + 1e-300), key
+
+
+def test_chain_summary_pooled_initseq_and_a_real_run(api, oracle_mod):
+    """mcse_initseq: R/initseq.R on every chain's batch means (the device's own initseq on nchain * nout centred
+    columns), var.con pooled, against the oracle's initseq chain by chain; then the summary of an actual batched run:
+    the three standard errors of the grand mean agree with each other and the chains agree (rhat ~ 1)."""
+    rng = np.random.default_rng(11)
+    nchain, nbatch, nout = 6, 400, 3
+    e = rng.standard_normal((nchain, nbatch, nout))
+    b = np.empty_like(e)
+    b[:, 0] = e[:, 0]
+    for t in range(1, nbatch):
+        b[:, t] = 0.6 * b[:, t - 1] + e[:, t]                # autocorrelated batch means: initseq has something to find
+    b += 5.0
+    ref = oracle_mod.chain_summary(b, with_initseq=True)
+    got = api.chain_summary(b, initseq=True)
+    assert np.all(np.abs(got["mcse_initseq"] - ref["mcse_initseq"]) <= 1e-10 * ref["mcse_initseq"])
+    assert np.all(got["mcse_initseq"] > 1.5 * got["mcse_within"])      # rho = 0.6: batch means understate, initseq does not
+    with pytest.raises(Exception, match="few long chains"):
+        api.chain_summary(np.zeros((70000, 4, 2)), initseq=True)
+    # a run: 512 chains on the logit posterior from the same start, device Philox
+    X, y = load_logit()
+    mle = glm_binomial(X, y)
+    out = api.metrop(api.logistic_target(X, y), np.tile(mle, (512, 1)), 50, 100, 1, scale=0.4, seed=5)
+    s = api.chain_summary(out["batch"])
+    assert s["nchain"] == 512 and s["nbatch"] == 50
+    assert np.all(np.abs(s["rhat"] - 1.0) < 0.05)
+    assert np.all(np.abs(s["mcse_between"] / s["mcse_within"] - 1.0) < 0.25)
+    assert np.all(np.abs(s["grand_mean"] - mle) < 0.2)        # posterior means sit near the MLE under the weak prior

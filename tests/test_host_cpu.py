@@ -221,6 +221,24 @@ for kw in ({"first_lags": 8}, {}):
         raise SystemExit("a halo of 8 rows cannot hold the stopping lag of the rho = 0.9 column")
     except RuntimeError as e:
         assert "beyond the halo" in str(e)
+# cross-chain diagnostics: every rank reduces its chains (numpy moments stand in for the device kernel), one all-gather
+# of 5 nout doubles per rank, merged in rank order by the library's host-only mcmchip_chain_summary_combine
+def np_summary(b):
+    b = np.asarray(b)
+    m = b.mean(axis=1)
+    s2 = ((b - m[:, None, :]) ** 2).sum(axis=1) / (b.shape[1] - 1)
+    gm = m.mean(axis=0)
+    stats = np.stack([np.full(b.shape[2], float(b.shape[0])), gm, ((m - gm) ** 2).sum(axis=0), s2.sum(axis=0),
+                      np.zeros(b.shape[2])])
+    return {"stats": stats, "nbatch": b.shape[1]}
+rngs = np.random.default_rng(17)
+ball = 2.0 + 1e-3 * rngs.standard_normal((11, 8, 3)) + 1e-3 * rngs.standard_normal((11, 1, 3))     # ragged: 6 + 5 chains
+lo, hi = mdist.shard_range(11, dist.get_rank(), 2)
+summ = mdist.chain_summary_sharded(np_summary, api.chain_summary_combine, ball[lo:hi])
+sref = oracle.chain_summary(ball)
+assert summ["nchain"] == 11 and summ["local"]["stats"][0, 0] == hi - lo
+for key in ("grand_mean", "between", "within", "mcse_between", "mcse_within", "rhat"):
+    assert np.all(np.abs(summ[key] - sref[key]) <= 1e-12 * np.abs(sref[key])), key
 dist.destroy_process_group()
 print("ok")
 '''
