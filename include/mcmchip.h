@@ -290,6 +290,22 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *args, mcm
 
 int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *args, mcmchip_temper_out *out);
 
+/* The same calls over several GPUs of the node, from ONE process -- the reference's front ends make one native call
+ * per run (R/metrop.R:48-51, R/temper.R:66-68) and an R session is one process.  devices[0 .. ndev): HIP device
+ * indices (a device may be listed more than once: its blocks then run side by side on it).  The nchain chains (nens
+ * ensembles) are cut into ndev contiguous blocks that differ by at most one unit; one host thread per block runs the
+ * call above on its device with the descriptor replicated there (once, kept with `t` and released with it), Philox
+ * keyed by the global chain / ensemble id (args.chain_offset + block start), and writes its results at the block's
+ * place in the caller's arrays.  Results do not depend on the device list (metrop: with path AUTO the kernel is chosen
+ * from the whole call's chain count; bit for bit on the MFMA path and in temper, to rounding on the stream path,
+ * whose summation order follows the block's chain count).  mcmchip_init need not have been called for the listed
+ * devices.  device_ptrs = 1: every pointer must be readable and writable from every listed device.  The interrupt
+ * callback keeps running on the calling thread.  mcmchip_last_kernel_time then reports the first block's kernels. */
+int mcmchip_metrop_multi(const mcmchip_target *t, const mcmchip_metrop_args *args, mcmchip_metrop_out *out,
+                         const int32_t *devices, int32_t ndev);
+int mcmchip_temper_multi(const mcmchip_target *t, const mcmchip_temper_args *args, mcmchip_temper_out *out,
+                         const int32_t *devices, int32_t ndev);
+
 /* initseq -- replaces SEXP initseq(SEXP x) (mcmc.h:14, initseq.c:7-128), batched over `ncol`
  * series stored column-major x[t + len*c].  Input is used as given: the caller centres it
  * (R/initseq.R:4).  Output vectors have data-dependent length n_out[c] <= len/2

@@ -150,6 +150,8 @@ EXPORTS = [
     "mcmchip_logdens_noalloc",
     "mcmchip_metrop",
     "mcmchip_temper",
+    "mcmchip_metrop_multi",
+    "mcmchip_temper_multi",
     "mcmchip_initseq",
     "mcmchip_lagsums",
     "mcmchip_initseq_from_lagsums",

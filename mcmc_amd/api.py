@@ -58,6 +58,10 @@ def load_library():
     L.mcmchip_metrop.restype = C.c_int
     L.mcmchip_temper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mcmchip_temper.restype = C.c_int
+    L.mcmchip_metrop_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.mcmchip_metrop_multi.restype = C.c_int
+    L.mcmchip_temper_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.mcmchip_temper_multi.restype = C.c_int
     L.mcmchip_initseq.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64] + [C.c_void_p] * 8
     L.mcmchip_initseq.restype = C.c_int
     L.mcmchip_chain_summary.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
@@ -177,7 +181,7 @@ def logdens(target, states, path=abi.PATH_AUTO):
 
 # ---------------------------------------------------------------------------------------------
 def metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=None, outfun=None, debug=None,
-           seed=None, z=None, u=None, path=abi.PATH_AUTO, chain_offset=0, _iter_offset=0):
+           seed=None, z=None, u=None, path=abi.PATH_AUTO, chain_offset=0, _iter_offset=0, devices=None):
     """metrop(obj, initial, nbatch, blen = 1, nspac = 1, scale = 1, outfun, debug = FALSE)
 
     obj     a Target, or the dict returned by a previous call (then missing arguments default
@@ -187,6 +191,8 @@ def metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=None, ou
             results gain a leading chain axis)
     seed    key of the device Philox stream (the role of .Random.seed); z, u: injected streams
             (parity mode)
+    devices list of HIP device indices: the chains are split over them inside this one call
+            (mcmchip_metrop_multi: one host thread per entry, descriptor replicated, same results)
     Returns a dict with the reference's names: accept, batch, initial, final, accept.batch
     [, current, proposal, log.green, u, z, debug.accept], initial.seed, final.seed, time, lud,
     nbatch, blen, nspac, scale, outfun, debug.
@@ -226,7 +232,12 @@ def metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=None, ou
                           seed=seed or 0, chain_offset=chain_offset, iter_offset=_iter_offset,
                           debug=debug, path=path)
     t0 = time.perf_counter()
-    _check(load_library().mcmchip_metrop(target.handle, C.addressof(call.args), C.addressof(call.out)))
+    if devices is None:
+        _check(load_library().mcmchip_metrop(target.handle, C.addressof(call.args), C.addressof(call.out)))
+    else:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(load_library().mcmchip_metrop_multi(target.handle, C.addressof(call.args), C.addressof(call.out),
+                                                   devs.ctypes.data, devs.size))
     elapsed = time.perf_counter() - t0
     r = call.result()
 
@@ -319,7 +330,8 @@ def morph_metrop(obj, initial=None, nbatch=None, blen=None, nspac=None, scale=No
 
 
 def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None, scale=None, outfun=None,
-           debug=None, parallel=None, seed=None, unif=None, norm=None, ens_offset=0, _iter_offset=0, _path=0):
+           debug=None, parallel=None, seed=None, unif=None, norm=None, ens_offset=0, _iter_offset=0, _path=0,
+           devices=None):
     """temper(obj, initial, neighbors, nbatch, blen = 1, nspac = 1, scale = 1, outfun,
               debug = FALSE, parallel = FALSE)   -- R/temper.R:2-75
 
@@ -388,7 +400,12 @@ def temper(obj, initial=None, neighbors=None, nbatch=None, blen=None, nspac=None
                           unif=unif, norm=norm, seed=seed or 0, ens_offset=ens_offset,
                           iter_offset=_iter_offset, debug=debug, out_kind=out_kind, path=_path, out_index=out_index)
     t0 = time.perf_counter()
-    _check(load_library().mcmchip_temper(target.handle, C.addressof(call.args), C.addressof(call.out)))
+    if devices is None:
+        _check(load_library().mcmchip_temper(target.handle, C.addressof(call.args), C.addressof(call.out)))
+    else:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(load_library().mcmchip_temper_multi(target.handle, C.addressof(call.args), C.addressof(call.out),
+                                                   devs.ctypes.data, devs.size))
     elapsed = time.perf_counter() - t0
     r = call.result()
 

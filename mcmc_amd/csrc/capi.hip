@@ -23,8 +23,42 @@ LibCtx &lib_ctx()
     return c;
 }
 
+static thread_local DeviceCtx *tl_dc = nullptr;           // set in the worker threads of a *_multi call
+static thread_local TimingState *tl_timing = nullptr;
+static thread_local volatile int *tl_abort = nullptr;
+
+WorkerScope::WorkerScope(DeviceCtx *dc, TimingState *timing, volatile int *abort_word)
+{
+    tl_dc = dc;
+    tl_timing = timing;
+    tl_abort = abort_word;
+}
+WorkerScope::~WorkerScope()
+{
+    tl_dc = nullptr;
+    tl_timing = nullptr;
+    tl_abort = nullptr;
+}
+
+static TimingState &cur_timing()
+{
+    if (tl_timing) return *tl_timing;
+    LibCtx &L = lib_ctx();
+    L.last_timing = &L.timing;
+    return L.timing;
+}
+
+int cur_device_index() { return tl_dc ? tl_dc->device : lib_ctx().device; }
+
 DeviceCtx *cur_dev()
 {
+    if (tl_dc) {
+        if (hipSetDevice(tl_dc->device) != hipSuccess) {
+            set_error(MCMCHIP_EHIP, "hipSetDevice(%d) failed", tl_dc->device);
+            return nullptr;
+        }
+        return tl_dc;
+    }
     LibCtx &L = lib_ctx();
     if (L.device < 0 || !L.dev[L.device].inited) {
         set_error(MCMCHIP_EHIP, "mcmchip_init() has not been called (no HIP device selected)");
@@ -39,30 +73,31 @@ DeviceCtx *cur_dev()
 
 void timing_reset(const char *name)
 {
-    LibCtx &L = lib_ctx();
-    L.ev_used = 0;
-    snprintf(L.ev_name, sizeof L.ev_name, "%s", name);
+    TimingState &T = cur_timing();
+    T.ev_used = 0;
+    snprintf(T.ev_name, sizeof T.ev_name, "%s", name);
 }
 // one event pair per timed launch; the pool grows with the longest call (EV_MAX only bounds a runaway loop)
 static const int EV_MAX = 1 << 20;
 void timing_begin(hipStream_t s)
 {
-    LibCtx &L = lib_ctx();
-    if (L.ev_used >= EV_MAX) return;
-    if ((int)L.ev_start.size() <= L.ev_used) {
+    TimingState &T = cur_timing();
+    if (T.ev_used >= EV_MAX) return;
+    if ((int)T.ev_start.size() <= T.ev_used) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-        L.ev_start.push_back(a);
-        L.ev_stop.push_back(b);
+        T.ev_start.push_back(a);
+        T.ev_stop.push_back(b);
+        T.device = cur_device_index();
     }
-    (void)hipEventRecord(L.ev_start[L.ev_used], s);
+    (void)hipEventRecord(T.ev_start[T.ev_used], s);
 }
 void timing_end(hipStream_t s)
 {
-    LibCtx &L = lib_ctx();
-    if (L.ev_used >= EV_MAX || (int)L.ev_stop.size() <= L.ev_used) return;
-    (void)hipEventRecord(L.ev_stop[L.ev_used], s);
-    L.ev_used++;
+    TimingState &T = cur_timing();
+    if (T.ev_used >= EV_MAX || (int)T.ev_stop.size() <= T.ev_used) return;
+    (void)hipEventRecord(T.ev_stop[T.ev_used], s);
+    T.ev_used++;
 }
 
 // Inputs handed over as device pointers are validated on the device: the reference refuses a non-finite `initial`
@@ -103,11 +138,11 @@ int device_validate(DeviceCtx *dc, const double *v, long n, long stride, int k, 
 
 double timing_last_ms()
 {
-    LibCtx &L = lib_ctx();
-    if (L.ev_used <= 0 || (int)L.ev_stop.size() < L.ev_used) return -1.0;
+    TimingState &T = cur_timing();
+    if (T.ev_used <= 0 || (int)T.ev_stop.size() < T.ev_used) return -1.0;
     float ms = 0.f;
-    if (hipEventSynchronize(L.ev_stop[L.ev_used - 1]) != hipSuccess) return -1.0;
-    if (hipEventElapsedTime(&ms, L.ev_start[L.ev_used - 1], L.ev_stop[L.ev_used - 1]) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(T.ev_stop[T.ev_used - 1]) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, T.ev_start[T.ev_used - 1], T.ev_stop[T.ev_used - 1]) != hipSuccess) return -1.0;
     return (double)ms;
 }
 
@@ -129,8 +164,35 @@ long next_launch_iters(long remaining, long last_iters, double last_ms, long ali
 
 int poll_interrupt()
 {
+    if (tl_abort)        // a worker of a *_multi call: the calling thread runs the callback and raises this word
+        return *tl_abort ? set_error(MCMCHIP_EINTR, "interrupted between two kernel launches") : MCMCHIP_OK;
     LibCtx &L = lib_ctx();
     if (L.poll && L.poll(L.poll_ctx)) return set_error(MCMCHIP_EINTR, "interrupted between two kernel launches");
+    return MCMCHIP_OK;
+}
+
+int init_device_ctx(int device, DeviceCtx &D)
+{
+    HIP_TRY(hipSetDevice(device));
+    if (D.inited) return MCMCHIP_OK;
+    D.device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    D.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&D.side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&D.join_ev[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&D.fork_ev, hipEventDisableTiming));
+    SoftplusTables host;
+    softplus_tables_init(&host);
+    HIP_TRY(hipMalloc((void **)&D.d_tables, sizeof host));
+    HIP_TRY(hipMemcpy(D.d_tables, &host, sizeof host, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&D.d_flag, 256));
+    HIP_TRY(hipMemset(D.d_flag, 0, 256));
+    if (int rc = mfma_scratch_setup(&D)) return rc;      // this device's address of the no-alloc scratch array
+    D.inited = true;
     return MCMCHIP_OK;
 }
 
@@ -162,28 +224,8 @@ int mcmchip_init(int device)
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device >= ndev) return set_error(MCMCHIP_EHIP, "device %d requested but only %d visible", device, ndev);
-    HIP_TRY(hipSetDevice(device));
     LibCtx &L = lib_ctx();
-    DeviceCtx &D = L.dev[device];
-    if (!D.inited) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        D.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipStreamCreateWithFlags(&D.side[i], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&D.join_ev[i], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&D.fork_ev, hipEventDisableTiming));
-        SoftplusTables host;
-        softplus_tables_init(&host);
-        HIP_TRY(hipMalloc((void **)&D.d_tables, sizeof host));
-        HIP_TRY(hipMemcpy(D.d_tables, &host, sizeof host, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&D.d_flag, 256));
-        HIP_TRY(hipMemset(D.d_flag, 0, 256));
-        if (int rc = mfma_scratch_setup(&D)) return rc;      // this device's address of the no-alloc scratch array
-        D.inited = true;
-    }
+    if (int rc = init_device_ctx(device, L.dev[device])) return rc;
     L.device = device;
     return MCMCHIP_OK;
 }
@@ -199,18 +241,23 @@ int mcmchip_sync(void)
 int mcmchip_last_kernel_time(double *avg_ms, int64_t *launches, char *name, int name_cap)
 {
     LibCtx &L = lib_ctx();
+    TimingState &T = L.last_timing ? *L.last_timing : L.timing;
+    int back = -1;
+    if (T.device >= 0 && hipGetDevice(&back) == hipSuccess && back != T.device) (void)hipSetDevice(T.device);
+    else back = -1;
     double tot = 0.0;
     int n = 0;
-    for (int i = 0; i < L.ev_used; i++) {
+    for (int i = 0; i < T.ev_used; i++) {
         float ms = 0.f;
-        if (hipEventSynchronize(L.ev_stop[i]) != hipSuccess) continue;
-        if (hipEventElapsedTime(&ms, L.ev_start[i], L.ev_stop[i]) != hipSuccess) continue;
+        if (hipEventSynchronize(T.ev_stop[i]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, T.ev_start[i], T.ev_stop[i]) != hipSuccess) continue;
         tot += ms;
         n++;
     }
+    if (back >= 0) (void)hipSetDevice(back);
     if (avg_ms) *avg_ms = n ? tot / n : 0.0;
     if (launches) *launches = n;
-    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", L.ev_name);
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", T.ev_name);
     return MCMCHIP_OK;
 }
 
@@ -233,7 +280,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
     if (desc->d <= 0) return set_error(MCMCHIP_EINVAL, "descriptor dimension must be positive");
     mcmchip_target *t = new (std::nothrow) mcmchip_target();
     if (!t) return set_error(MCMCHIP_EHIP, "out of host memory");
-    t->kind = desc->kind; t->d = desc->d; t->prior_c = desc->prior_c; t->device = lib_ctx().device;
+    t->kind = desc->kind; t->d = desc->d; t->prior_c = desc->prior_c; t->device = dc->device;
     hipMemcpyKind kind = desc_device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     int rc = MCMCHIP_OK;
     try {
@@ -331,6 +378,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
 void mcmchip_target_destroy(mcmchip_target *t)
 {
     if (!t) return;
+    for (mcmchip_target *r : t->replicas) mcmchip_target_destroy(r);      // hipFree takes a pointer of any device
     if (t->x) (void)hipFree(t->x);
     if (t->y) (void)hipFree(t->y);
     if (t->par) (void)hipFree(t->par);
@@ -358,8 +406,8 @@ static int check_flag(DeviceCtx *dc, bool temper)
 // a descriptor lives in the HBM of the device that was current when it was created
 static int check_target_device(const mcmchip_target *t)
 {
-    if (t->device != lib_ctx().device)
-        return set_error(MCMCHIP_EINVAL, "descriptor was created on device %d, the current device is %d", t->device, lib_ctx().device);
+    if (t->device != cur_device_index())
+        return set_error(MCMCHIP_EINVAL, "descriptor was created on device %d, the current device is %d", t->device, cur_device_index());
     return MCMCHIP_OK;
 }
 

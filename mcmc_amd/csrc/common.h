@@ -15,6 +15,7 @@
 
 struct DeviceCtx {
     bool inited = false;
+    int device = -1;                     // HIP device this context lives on
     hipStream_t stream = nullptr;
     SoftplusTables *d_tables = nullptr;  // softplus tables in HBM
     int *d_flag = nullptr;               // error flag word shared by the kernels
@@ -31,14 +32,20 @@ struct DeviceCtx {
 };
 #define MCMCHIP_WS_KEEP ((size_t)2 << 30)
 
+// timing of the dominant kernel of a call (HIP events on the stream it runs on)
+struct TimingState {
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    int ev_used = 0;
+    char ev_name[64] = {0};
+    int device = -1;                     // device the events were created on
+};
+
 // per-process state (one process per GPU in the multi-GPU launch, but any device may be selected)
 struct LibCtx {
     int device = -1;
     DeviceCtx dev[MCMCHIP_MAX_DEVICES];
-    // timing of the dominant kernel of the last call (HIP events on our stream)
-    std::vector<hipEvent_t> ev_start, ev_stop;
-    int ev_used = 0;
-    char ev_name[64] = {0};
+    TimingState timing;                  // of calls made on the caller's thread
+    TimingState *last_timing = nullptr;  // what mcmchip_last_kernel_time reports (a *_multi call: its first worker's)
     // persistent sampler kernels are cut into launches of about launch_budget_s seconds (max_iters_per_launch > 0
     // fixes the iterations per launch instead); between launches the host calls `poll` (R_CheckUserInterrupt's
     // place, metrop.c:269 / temper.c:848): a non-zero return abandons the call with MCMCHIP_EINTR
@@ -50,6 +57,16 @@ struct LibCtx {
 
 LibCtx &lib_ctx();
 DeviceCtx *cur_dev();  // nullptr (and error set) when mcmchip_init has not succeeded
+int cur_device_index();            // device of cur_dev() (-1: none)
+int init_device_ctx(int device, DeviceCtx &D);      // streams, softplus tables, flag words on `device` (made current)
+
+// A worker thread of a *_multi call (multi.hip) runs the ordinary entry points against a context of its own: its
+// device context (own streams, flag words, MFMA workspace), its kernel timing, and an abort word in place of the
+// caller's interrupt callback, which only the calling thread may run (R_CheckUserInterrupt is not thread safe).
+struct WorkerScope {
+    WorkerScope(DeviceCtx *dc, TimingState *timing, volatile int *abort_word);
+    ~WorkerScope();
+};
 
 int set_error(int code, const char *fmt, ...);
 void clear_error();
@@ -168,6 +185,8 @@ struct mcmchip_target {
     double *xt = nullptr;
     double *colsum = nullptr;  // [dpad] column sums of the sign-folded X (sum_i eta_i = colsum . theta)
     int device = 0;
+    // copies in the HBM of other devices, made on demand by the *_multi entry points and released with the original
+    std::vector<mcmchip_target *> replicas;
 };
 
 // kernel timing hooks (metrop_mfma.hip uses them around the log-density launches)

@@ -159,12 +159,32 @@ SEXP glue_seed_to_sexp(uint64_t key, uint64_t iter_offset, uint64_t unit_offset)
 static void check_interrupt(void *unused) { (void)unused; R_CheckUserInterrupt(); }
 static int poll_r_interrupt(void *unused) { (void)unused; return R_ToplevelExec(check_interrupt, NULL) == FALSE; }
 
+/* MCMCHIP_DEVICES="0,1,2,3,4,5,6,7": the descriptor natives split the chains (ensembles) of every call over these
+ * GPUs of the node through mcmchip_metrop_multi / mcmchip_temper_multi -- one .Call, one R process, several devices
+ * (R/metrop.R:48-51 makes exactly one native call per run).  Unset or a single entry: the one device of
+ * glue_init_device.  Returns the number of entries written to devices[0 .. cap). */
+int glue_device_list(int *devices, int cap)
+{
+    const char *e = getenv("MCMCHIP_DEVICES");
+    int n = 0;
+    while (e && *e && n < cap) {
+        char *end;
+        const long v = strtol(e, &end, 10);
+        if (end == e) break;
+        devices[n++] = (int)v;
+        e = *end == ',' ? end + 1 : end;
+    }
+    return n;
+}
+
 void glue_init_device(void)
 {
     static int done = 0;
     if (done) return;
     const char *e = getenv("MCMCHIP_DEVICE");
-    int rc = mcmchip_init(e ? atoi(e) : 0);
+    int first[1];
+    /* the descriptor lives on the first listed device; the others receive replicas on first use */
+    int rc = mcmchip_init(e ? atoi(e) : (glue_device_list(first, 1) ? first[0] : 0));
     if (rc) glue_raise(rc);
     mcmchip_set_interrupt_poll(poll_r_interrupt, NULL);
     done = 1;

@@ -22,6 +22,7 @@ void glue_seed_from_sexp(SEXP seed, uint64_t *key, uint64_t *iter_offset, uint64
 SEXP glue_seed_to_sexp(uint64_t key, uint64_t iter_offset, uint64_t unit_offset);
 /* select the device once (environment variable MCMCHIP_DEVICE, default 0) and install the interrupt poll */
 void glue_init_device(void);
+int glue_device_list(int *devices, int cap);   /* MCMCHIP_DEVICES, comma separated */
 /* release what the caller lists, then raise the library's last error as an R error */
 void glue_raise(int rc);
 

@@ -140,7 +140,9 @@ SEXP metrop_descriptor(SEXP desc, SEXP initial, SEXP nbatch, SEXP blen, SEXP nsp
         o.log_green = REAL(dlg); o.u = REAL(du);
         o.debug_accept = LOGICAL(dacc);     /* int32 0/1 */
     }
-    const int rc = mcmchip_metrop(target, &a, &o);   /* device buffers are released inside before it returns */
+    int devices[64];
+    const int ndev = glue_device_list(devices, 64);          /* MCMCHIP_DEVICES: several GPUs behind this one .Call */
+    const int rc = ndev > 1 ? mcmchip_metrop_multi(target, &a, &o, devices, ndev) : mcmchip_metrop(target, &a, &o);   /* device buffers are released inside before it returns */
     if (rc) glue_raise(rc);
     if (int_debug)                           /* the reference stores NA where no uniform was drawn (metrop.c:252-255) */
         for (R_xlen_t i = 0; i < XLENGTH(du); i++)

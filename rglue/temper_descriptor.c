@@ -159,7 +159,9 @@ SEXP temper_descriptor(SEXP desc, SEXP initial, SEXP neighbors, SEXP nbatch, SEX
     o.acceptx = REAL(acceptx);
     o.accepti = REAL(accepti);
     o.final = REAL(final_);
-    const int rc = mcmchip_temper(target, &a, &o);
+    int devices[64];
+    const int ndev = glue_device_list(devices, 64);          /* MCMCHIP_DEVICES: several GPUs behind this one .Call */
+    const int rc = ndev > 1 ? mcmchip_temper_multi(target, &a, &o, devices, ndev) : mcmchip_temper(target, &a, &o);
     if (rc) glue_raise(rc);
     /* NaN markers of the C-ABI -> NA_real_ where the reference stores NA (temper.c:593-609,762,833,896-897) */
     for (int i = 0; i < ncomp * ncomp; i++)

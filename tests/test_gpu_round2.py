@@ -1010,3 +1010,73 @@ def test_chain_summary_pooled_initseq_and_a_real_run(api, oracle_mod):
     assert np.all(np.abs(s["rhat"] - 1.0) < 0.05)
     assert np.all(np.abs(s["mcse_between"] / s["mcse_within"] - 1.0) < 0.25)
     assert np.all(np.abs(s["grand_mean"] - mle) < 0.2)        # posterior means sit near the MLE under the weak prior
+
+
+# ----------------------------------------------------------------------------- one call, several devices
+def test_metrop_and_temper_multi_device_list(api, oracle_mod):
+    """mcmchip_metrop_multi / mcmchip_temper_multi: one call, the chains (ensembles) split over a device list, one host
+    thread per entry.  The test box has one GPU, so the list is [0, 0] / [0, 0, 0]: blocks side by side on one device,
+    each worker with a context of its own (streams, flag words, MFMA workspace).  MFMA path and temper: bit for bit the
+    single call, Philox and injected streams, ragged blocks, more devices than chains; stream path: same decisions."""
+    rng = np.random.default_rng(21)
+    n, d, Cn = 4096, 16, 301                                  # ragged over 2 and 3 blocks
+    X = rng.standard_normal((n, d)) / 4
+    X[:, 0] = 1.0
+    y = (rng.random(n) < 0.5).astype(float)
+    tg = api.logistic_target(X, y)
+    init = 0.05 * rng.standard_normal((Cn, d))
+    one = api.metrop(tg, init, 4, 3, 2, scale=0.02, seed=99, path=abi.PATH_MFMA)
+    for devs in ([0, 0], [0, 0, 0], [0]):
+        many = api.metrop(tg, init, 4, 3, 2, scale=0.02, seed=99, path=abi.PATH_MFMA, devices=devs)
+        for key in ("accept", "batch", "final", "accept.batch"):
+            assert np.array_equal(one[key], many[key]), (devs, key)
+    # AUTO is resolved on the whole call (here: the MFMA kernel), not per block
+    auto1 = api.metrop(tg, init, 4, 3, 2, scale=0.02, seed=99)
+    auto2 = api.metrop(tg, init, 4, 3, 2, scale=0.02, seed=99, devices=[0, 0, 0, 0, 0])
+    assert np.array_equal(auto1["batch"], auto2["batch"])
+    # injected streams and the debug trace (stream path), small posterior; more devices than chains
+    Xl, yl = load_logit()
+    tl = api.logistic_target(Xl, yl)
+    i5 = 0.1 * rng.standard_normal((5, 5))
+    niter = 6
+    z, u = rng.standard_normal((5, niter, 5)), rng.random((5, niter))
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, 5, x=Xl, y=yl, prior_c=0.125), i5, 3, 2, 1, scale=0.4, z=z, u=u,
+                            debug=True)
+    got = api.metrop(tl, i5, 3, 2, 1, scale=0.4, z=z, u=u, debug=True, devices=[0] * 7)
+    assert np.array_equal(got["final"], ref["final"]) and np.array_equal(got["batch"], ref["batch"])
+    assert np.array_equal(got["proposal"], ref["proposal"]) and np.array_equal(got["debug.accept"], ref["debug_accept"])
+    # an error in one block is the call's error: chain 3 starts outside the unit ball
+    ball = api.Target(abi.T_BALL, 2)
+    bad = np.zeros((6, 2))
+    bad[3] = [2.0, 0.0]
+    with pytest.raises(Exception, match="-Inf at initial state"):
+        api.metrop(ball, bad, 5, scale=0.1, seed=1, devices=[0, 0])
+    # temper: ensembles split, both kernels' shapes
+    k, p, E = 6, 2, 11
+    par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.arange(k) / p)
+    wt = api.Target(abi.T_WITCH, p, par=par)
+    nb = np.abs(np.subtract.outer(np.arange(k), np.arange(k))) == 1
+    t1 = api.temper(wt, np.zeros((E, k, p)), nb, 5, 4, 3, 0.3, parallel=True, seed=8)
+    t2 = api.temper(wt, np.zeros((E, k, p)), nb, 5, 4, 3, 0.3, parallel=True, seed=8, devices=[0, 0, 0])
+    for key in ("batch", "acceptx", "accepti", "final"):
+        assert np.array_equal(t1[key], t2[key], equal_nan=True), key
+    s0 = np.tile(np.concatenate([[1.0], np.zeros(p)]), (E, 1))
+    s1 = api.temper(wt, s0, nb, 5, 4, 3, 0.3, parallel=False, seed=8, debug=True)
+    s2 = api.temper(wt, s0, nb, 5, 4, 3, 0.3, parallel=False, seed=8, debug=True, devices=[0, 0])
+    for key in ("batch", "ibatch", "acceptx", "accepti", "final", "state", "proposal", "unif.choose", "log.hastings"):
+        assert np.array_equal(s1[key], s2[key], equal_nan=True), key
+    # the interrupt callback runs on the calling thread and stops every block
+    calls = []
+    api.set_interrupt_poll(lambda: calls.append(1) or len(calls) > 3)
+    api.load_library().mcmchip_set_launch_limit(64, 0.0)
+    try:
+        with pytest.raises(Exception, match="interrupted"):
+            api.metrop(tl, np.tile(i5, (200, 1)), 20000, scale=0.4, seed=3, devices=[0, 0])
+    finally:
+        api.set_interrupt_poll(None)
+        api.load_library().mcmchip_set_launch_limit(0, 0.0)
+    # bad lists
+    with pytest.raises(Exception, match="device"):
+        api.metrop(tl, i5, 3, scale=0.4, seed=1, devices=[0, 99])
+    with pytest.raises(Exception, match="device list"):
+        api.metrop(tl, i5, 3, scale=0.4, seed=1, devices=[])
