@@ -90,6 +90,9 @@ def main():
                     help="strong: --chains split over the GPUs (default for --gpus > 1); weak: --chains per GPU")
     ap.add_argument("--scale", type=float, default=4.0e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (BASELINE configs 2, 4 and 5 on the device; N = 1 only)")
+    ap.add_argument("--secondary", default="c2,c4,c5", help="which secondary configs to run")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the collectives go through "
                          "gloo on host copies (RCCL refuses two ranks on one device); exercises the sharding, not the fabric")
@@ -181,13 +184,21 @@ def main():
         elapsed = float(tmax.item())
 
     kname, kms, klaunch = api.last_kernel_time()
-    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
-    # process, so the recorded rocprofv3 measurement of the same workload is reported (or null)
-    traffic = None
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the recorded
+    # rocprofv3 measurement of the same workload is reported -- only while it is a measurement of THIS kernel: the record
+    # carries a hash of the kernel's sources (tools/kernel_source_hash.py) and a change of theirs turns it into null
+    traffic, traffic_src = None, None
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
-        if rec["workload"] == {"n": a.n, "d": a.d, "chains_per_gpu": Cn}:
-            traffic = rec["hbm_bytes_per_launch"]
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kernel_source_hash import logdens_kernel_hash
+        for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):
+            f = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(f):
+                continue
+            rec = json.load(open(f))
+            if rec["workload"] == {"n": a.n, "d": a.d, "chains_per_gpu": Cn} and rec.get("kernel_source_sha256") == logdens_kernel_hash(ROOT):
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/" + name
+                break
     except Exception:
         pass
     if rank == 0:
@@ -210,7 +221,8 @@ def main():
                        "note": "timed call = %d iterations + the call's initial-state density evaluation" % a.steps},
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_pmc_traffic.json)",
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this workload and these "
+                                         "kernel sources: %s)" % (traffic_src or "no record matches: null"),
                          "launch_ms": kms, "launches_timed": klaunch,
                          "flops_per_launch": flops_per_launch},
         }
@@ -219,6 +231,12 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(X, y, beta, a.scale)
             except Exception as e:          # the baseline is a reported extra, never the product path
                 res["cpu_baseline"] = {"value": None, "error": str(e)}
+        if world == 1 and not a.no_secondary:
+            # BASELINE configs 2, 4 and 5 beside the headline (config 3); device path only, after the timed region
+            del out_batch_buf, out_ab
+            torch.cuda.empty_cache()
+            import bench_secondary
+            res["secondary"] = bench_secondary.run(api, torch, dev, tuple(w for w in a.secondary.split(",") if w))
         print(json.dumps(res))
     if use_dist:
         dist.barrier()

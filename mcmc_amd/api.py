@@ -484,11 +484,13 @@ def initseq(x, centred=False):
     """initseq(x): R/initseq.R:1-5 -- x numeric, all finite; the series is centred here and the
     centred series goes to the native routine.  A 2-d x (len x ncol) is a batch of series and
     returns a list of results.
-    A DeviceSeries (upload_series) is taken as the native routine takes its argument (initseq.c:7): centred already,
-    which the caller states with centred = True; the device checks that it is finite."""
-    if isinstance(x, DeviceSeries):
+    A DeviceSeries (upload_series) or a float64 CUDA tensor of shape (ncol, len) is taken as the native routine takes its
+    argument (initseq.c:7): centred already, which the caller states with centred = True; the device checks that it is
+    finite."""
+    if isinstance(x, DeviceSeries) or (hasattr(x, "data_ptr") and hasattr(x, "is_cuda")):
+        # resident in HBM already (a DeviceSeries, or a contiguous float64 CUDA tensor of shape (ncol, len))
         if not centred:
-            raise ValueError("a DeviceSeries goes to the native routine as it is: centre it first and pass centred=True")
+            raise ValueError("a series in HBM goes to the native routine as it is: centre it first and pass centred=True")
         single = False
         src = x
     else:

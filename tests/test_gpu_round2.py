@@ -1080,3 +1080,105 @@ def test_metrop_and_temper_multi_device_list(api, oracle_mod):
         api.metrop(tl, i5, 3, scale=0.4, seed=1, devices=[0, 99])
     with pytest.raises(Exception, match="device list"):
         api.metrop(tl, i5, 3, scale=0.4, seed=1, devices=[])
+
+
+# ----------------------------------------------------------------------------- BASELINE configs 4 and 5 at full size
+@pytest.mark.parametrize("target", ["witch", "mixture"])
+def test_c4_full_size_64_temperatures_1024_ensembles_vs_oracle(api, oracle_mod, target):
+    """BASELINE.json config 4 at its size: k = 64 temperatures (tri-diagonal neighbours), 1024 ensembles, parallel
+    tempering; 600 iterations with injected streams, EVERY ensemble against the oracle (16 threads): final states and
+    the acceptance tables bit for bit, batch means to 1e-12; the run kernel (the one C4 takes) and the LDS kernel."""
+    rng = np.random.default_rng(64)
+    k, E, nbatch, blen, nspac = 64, 1024, 10, 6, 10
+    niter = nbatch * blen * nspac
+    if target == "witch":
+        p = 3
+        par = 1 - 0.5 ** (1 / p) * 0.25 ** (np.linspace(0, 5, k) / p)
+        K, x0 = abi.T_WITCH, np.zeros(p)
+    else:
+        p = 2
+        par = np.concatenate([[float(k)], np.geomspace(1.0, 0.01, k), abi.normmix_par([0.5, 0.5], [[-4.0, -4.0], [4.0, 4.0]], 1.0)])
+        K, x0 = abi.T_TEMPERED_NORMMIX, np.array([4.0, 4.0])
+    i, j = np.indices((k, k))
+    nb = np.abs(i - j) == 1
+    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+    init = np.tile(x0, (E, k, 1))
+    ref = oracle_mod.temper(oracle_mod.Target(K, p, par=par), init, nb, nbatch, blen, nspac, 0.3, parallel=True,
+                            unif=unif, norm=norm, nthreads=16)
+    for path in (abi.PATH_RUN, abi.PATH_LDS):
+        o = api.temper(api.Target(K, p, par=par), init, nb, nbatch, blen, nspac, 0.3, parallel=True, unif=unif, norm=norm,
+                       _path=path)
+        assert np.array_equal(o["final"], ref["final"]), path
+        assert np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True), path
+        assert np.array_equal(o["accepti"], ref["accepti"], equal_nan=True), path
+        assert rel(o["batch"] + 10, ref["batch"] + 10) < 1e-12, path
+    assert np.nanmean(ref["acceptx"]) > 0.05 and np.nanmean(ref["accepti"]) > 0.05        # the chains move and swap
+
+
+def test_c5_full_size_by_properties(api):
+    """BASELINE.json config 5 at its size: 1e8 steps x 256 AR(1) functionals, 204.8 GB resident (generated on the device,
+    bench_secondary.ar1_columns).  The oracle cannot follow here (it covers n <= 1e7 elsewhere); size-independent
+    properties instead:
+      initseq  var.con / gamma0 against the AR(1) value (1 + rho) / (1 - rho); duplicated columns give the same bits; the
+               identities of tests/initseq.R (cummin, last element 0, variance identity) on every column; a time-sharded
+               evaluation (two halves + halo, raw lag sums added) equals the unsharded one to 1e-10
+      olbm     diagonal against n var = gamma0 (1 + rho) / (1 - rho) within the estimator's own error; symmetric; the means
+               route and the supplied-means route agree to 1e-10."""
+    import torch
+    import bench_secondary
+    from mcmc_amd import dist as mdist
+    dev = torch.device("cuda", 0)
+    n, p, blen = 100_000_256, 256, 10_000
+    x = bench_secondary.ar1_columns(n, p, torch, dev)
+    x[7] = x[200]                                           # duplicated columns (a long one over a short one)
+    x[255] = x[254]
+    rho = 0.5 + 0.49 * np.arange(p) / (p - 1)
+    rho[7], rho[255] = rho[200], rho[254]
+    res = api.initseq(x, centred=True)
+    g0 = np.array([r["gamma0"] for r in res])
+    vc = np.array([r["var.con"] for r in res])
+    theory = (1 + rho) / (1 - rho)
+    # var.con / gamma0 estimates (1 + rho) / (1 - rho) with relative error ~ sqrt(2 (1 + rho) / ((1 - rho) n)) x a few
+    tol = 6 * np.sqrt(2 * theory / n) + 0.01
+    assert np.all(np.abs(vc / g0 / theory - 1) < tol), np.max(np.abs(vc / g0 / theory - 1) / tol)
+    assert np.all(np.abs(g0 * (1 - rho * rho) - 1) < 6 * np.sqrt(2 * theory / n) + 0.005)      # gamma0 = 1 / (1 - rho^2)
+    for a, b in ((7, 200), (255, 254)):
+        for key in ("gamma0", "Gamma.pos", "Gamma.con", "var.con"):
+            assert np.array_equal(res[a][key], res[b][key]), (a, key)
+    for r in res:
+        assert np.array_equal(r["Gamma.dec"], np.minimum.accumulate(r["Gamma.pos"]))
+        assert r["Gamma.pos"][-1] == 0 and r["Gamma.dec"][-1] == 0
+        assert np.isclose(2 * r["Gamma.con"].sum() - r["gamma0"], r["var.con"], rtol=1e-12)
+    # sharded by time: two ranks emulated in turn on views of the resident series (no copy of 100 GB: the second rank's
+    # block is a strided view made contiguous column by column inside lagsums' contract -> use 8 columns)
+    cols = [0, 100, 200, 254, 7, 31, 128, 255]
+    halo = 2048
+    total = None
+    for r in range(2):
+        lo, hi, own = mdist.initseq_time_shard(n, halo, r, 2)
+        blk = torch.stack([x[c, lo:hi] for c in cols]).contiguous()          # 8 x (n/2 + halo): 3.2 GB
+        part = api.lagsums(blk, halo)
+        if hi - lo > own:
+            part = part - api.lagsums(blk[:, own:].contiguous(), halo)
+        total = part if total is None else total + part
+        del blk
+    sh = api.initseq_from_lagsums(total, n)
+    for i_, c in enumerate(cols):
+        assert sh[i_] is not None and len(sh[i_]["Gamma.pos"]) == len(res[c]["Gamma.pos"]), c
+        for key in ("gamma0", "Gamma.pos", "Gamma.con", "var.con"):
+            a, b = np.asarray(sh[i_][key]), np.asarray(res[c][key])
+            assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(b)), (c, key)
+    # olbm
+    var, mean = api.olbm_device(x, blen)
+    assert np.array_equal(var, var.T)
+    var2, _ = api.olbm_device(x, blen, mean=mean)
+    assert np.max(np.abs(var - var2)) <= 1e-10 * np.max(np.abs(var))
+    # olbm estimates sigma^2 / n with sigma^2 = gamma0 (1 + rho) / (1 - rho), biased down by ~ (1 + rho) / ((1 - rho) len)-ish
+    # for len = 1e4 and noisy to ~ sqrt(len / n) = 1 %
+    s2 = theory / (1 - rho * rho)
+    ratio = np.diag(var) * n / s2
+    assert np.all(np.abs(ratio - 1) < 0.08), (ratio.min(), ratio.max())
+    assert np.all(np.abs(mean) < 6 * np.sqrt(s2 / n) + 1e-9)                  # the series was centred on the device
+    assert abs(var[7, 7] - var[200, 200]) <= 1e-12 * var[200, 200] and abs(var[7, 200] - var[200, 200]) <= 1e-12 * var[200, 200]
+    del x
+    torch.cuda.empty_cache()
