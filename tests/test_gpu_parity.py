@@ -923,8 +923,9 @@ def test_c_demo_matches_python_api(api, tmp_path):
     mirror with the same inputs and Philox seed must give the same bits (same library underneath)"""
     import subprocess
     exe = os.path.join(ROOT, "examples", "capi_demo")
-    if not os.path.exists(exe):              # a build artefact like the .so: __graft_entry__.build() makes it
-        pytest.skip("examples/capi_demo is not built (make -C examples)")
+    # a build artefact like the .so (__graft_entry__.build() makes it, it travels with the tree): its absence is a
+    # failure, not a skip -- this is the only test that drives the boundary from plain C
+    assert os.path.exists(exe), "examples/capi_demo is not built (make -C examples)"
     rng = np.random.default_rng(5)
     n, d, C, nbatch, blen, seed = 300, 4, 6, 60, 7, 20240611
     X = np.column_stack([np.ones(n), rng.standard_normal((n, d - 1))])

@@ -1182,3 +1182,61 @@ def test_c5_full_size_by_properties(api):
     assert abs(var[7, 7] - var[200, 200]) <= 1e-12 * var[200, 200] and abs(var[7, 200] - var[200, 200]) <= 1e-12 * var[200, 200]
     del x
     torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------------------- +Inf / NaN in the middle of a run
+def test_posinf_and_nan_mid_run_are_the_references_errors(api):
+    """logh() refuses +Inf and NA/NaN wherever they turn up (metrop.c:317-320; temper.c:971-974 for the density,
+    578-580 for the Hastings ratio).  Here the initial state is fine and a later proposal is not; the device finishes
+    the launch and then reports, in the reference's words, on every path: stream kernel, MFMA path, both temper kernels."""
+    z2 = np.zeros((3, 2))
+    # stream: a "normal" with precision -1e300 I is +Inf a step of 1e5 away; with precision diag(1.7e308, -1.7e308) it is
+    # Inf - Inf as soon as both coordinates exceed 1 (the device reports after the launch: were only one term to
+    # overflow in some later proposal, +Inf would be raised as well and named first)
+    for P, text in ((-1e300 * np.eye(2), r"logh: func returned \+Inf"), (np.diag([1.7e308, -1.7e308]), "logh: func returned NA or NaN")):
+        tg = api.Target(abi.T_MVNORM, 2, par=np.concatenate([np.zeros(2), P.ravel()]))
+        assert np.all(api.logdens(tg, z2) == 0.0)
+        for init in (z2, z2[0]):
+            with pytest.raises(Exception, match=text):
+                api.metrop(tg, init, 20, scale=1e5, seed=4, path=abi.PATH_STREAM)
+    # MFMA: the logistic posterior with a prior "precision" of the wrong sign: - prior_c sum(beta^2) with prior_c = -1e308
+    # is +Inf as soon as the chain has left the origin; prior_c = 0 and steps of 1e200 make the same term 0 * Inf
+    rng = np.random.default_rng(8)
+    n, d = 4096, 8
+    X = rng.standard_normal((n, d))
+    y = (rng.random(n) < 0.5).astype(float)
+    for prior_c, scale, text in ((-1e308, 5.0, r"logh: func returned \+Inf"), (0.0, 1e200, "logh: func returned NA or NaN")):
+        tg = api.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=prior_c)
+        assert np.all(np.isfinite(api.logdens(tg, np.zeros((2, d)))))
+        for path in (abi.PATH_MFMA, abi.PATH_STREAM):
+            with pytest.raises(Exception, match=text):
+                api.metrop(tg, np.zeros((128, d)), 6, scale=scale, seed=4, path=path)
+    # temper, LDS kernel: the model-selection posterior with the same priors
+    from rhelpers import temp_par_setup
+    Xf, yf, models, masks, betas, nb = temp_par_setup()
+    for prior_c, scale, text in ((-1e308, 5.0, r"log unnormalized density function returned \+Inf"),
+                                 (0.0, 1e200, "log unnormalized density function returned NA or NaN")):
+        tg = api.Target(abi.T_LOGISTIC_MODELS, 4, x=Xf, y=yf, prior_c=prior_c, par=abi.logistic_models_par(masks))
+        for parallel in (True, False):
+            init = np.zeros((5, 8, 4)) if parallel else np.tile(np.concatenate([[8.0], np.zeros(4)]), (5, 1))
+            with pytest.raises(Exception, match=text):
+                api.temper(tg, init, nb, 10, 4, 1, scale, parallel=parallel, seed=4)
+    # temper, run kernel (parallel, closed-form descriptor): h(i, x) = beta_i (10 - |x|^2) with beta_i = 5e307 overflows
+    # to +Inf inside |x|^2 < 6.4 ...
+    k = 4
+    i_, j_ = np.indices((k, k))
+    nbr = np.abs(i_ - j_) == 1
+    mix = np.array([1.0, 10.0, 1.0, 0.0, 0.0])                        # K = 1: a = 10, b = 1, mean 0
+    tg = api.Target(abi.T_TEMPERED_NORMMIX, 2, par=np.concatenate([[float(k)], np.full(k, 5e307), mix]))
+    init = np.tile([np.sqrt(12.0), 0.0], (4, k, 1))
+    for path in (abi.PATH_RUN, abi.PATH_LDS):
+        with pytest.raises(Exception, match=r"returned \+Inf"):
+            api.temper(tg, init, nbr, 20, 5, 1, 1.5, parallel=True, seed=4, _path=path)
+    # ... and an inverse temperature of 0 turns the -Inf the mixture takes once a step of 1e160 has overflowed |x|^2
+    # into 0 * -Inf
+    mix2 = np.array([1.0, 0.0, 1.0, 0.0, 0.0])
+    tg = api.Target(abi.T_TEMPERED_NORMMIX, 2, par=np.concatenate([[float(k)], [1.0, 0.5, 0.2, 0.0], mix2]))
+    init = np.tile([1.0, 0.0], (4, k, 1))
+    for path in (abi.PATH_RUN, abi.PATH_LDS):
+        with pytest.raises(Exception, match="returned NA or NaN"):
+            api.temper(tg, init, nbr, 20, 5, 1, 1e160, parallel=True, seed=4, _path=path)
