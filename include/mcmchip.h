@@ -280,7 +280,8 @@ int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchai
  * scratch (dimension-major states + per-split partial sums) lives in a fixed device array of
  * MCMCHIP_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends; the call makes no
  * hipMalloc / hipFree / event creation.  `states` (nchain x d) and `out` (nchain) are DEVICE pointers on the current
- * device; t must be a logistic descriptor with d <= 128.  Needs (dpad + nunits) * ceil(nchain / 256) * 256 doubles,
+ * device; t must be a logistic descriptor with d <= 256.  Needs (dpad + nunits) * ceil(nchain / W) * W doubles (W = 256
+ * chains a workgroup up to d = 128, 128 beyond; dpad = d rounded up to 8 / 16 / 64 for d <= 64 / <= 128 / <= 256),
  * nunits <= 256 the units the observations are summed in (e.g. 8192 chains at d = 64 with 256 units: 20 MiB); beyond the array it returns MCMCHIP_ECAP
  * with the required size in the message.  Calls on one GPU share the array: calls that overlap on one GPU race. */
 #define MCMCHIP_NOALLOC_SCRATCH_BYTES (32u << 20)

@@ -10,7 +10,7 @@
 #include "softplus.h"
 
 #define MCMCHIP_MAX_DEVICES 16
-#define MCMCHIP_MFMA_MAXD 128
+#define MCMCHIP_MFMA_MAXD 256
 #define MCMCHIP_NOALLOC_SCRATCH_DOUBLES (4L << 20)   // 32 MiB per GPU (include/mcmchip.h: MCMCHIP_NOALLOC_SCRATCH_BYTES)
 
 struct DeviceCtx {

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void tile_colsum_kernel(const double *__restri
 
 int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 {
-    t->dpad = t->d <= 64 ? ((t->d + 7) / 8) * 8 : ((t->d + 15) / 16) * 16;   // d > 64: k-steps in {20, 24, 28, 32}
+    // d > 64: k-steps in {20, 24, 28, 32}; d > 128: {48, 64} (whole turns of the kernel's 16-k-step fragment ring)
+    t->dpad = t->d <= 64 ? ((t->d + 7) / 8) * 8 : (t->d <= 128 ? ((t->d + 15) / 16) * 16 : ((t->d + 63) / 64) * 64);
     if (t->dpad < 8) t->dpad = 8;
     t->ksteps = t->dpad / 4;
     long tiles = (t->n + 15) / 16;
@@ -149,6 +150,10 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 {
     using P = TilePlan<KS, NC>;
     constexpr int GK = P::GK, NG = P::NG, NV = P::NV, NP = P::npend();
+    // X fragment registers: up to d = 128 one per k-step (the whole next tile is in flight behind this one); beyond, a
+    // ring of 16 k-steps -- the Theta fragments alone take 128 registers at d = 256 -- refilled 4 groups ahead of use
+    constexpr int AR = KS > 32 ? 16 : KS, LEAD = KS > 32 ? AR / GK : NG;
+    static_assert(KS <= 32 || (AR % GK == 0 && KS % GK == 0 && KS % AR == 0), "ring of whole groups");
     // LDS holds the softplus table only.  The X fragments go from global memory straight into registers: the waves
     // of a workgroup (and all workgroups of an XCD) read the same tiles at about the same time, so one of them pays
     // the HBM / L2 miss and the rest hit the CU's vector cache or the XCD's L2; no staging, no barrier in the loop.
@@ -181,13 +186,13 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
     // min(eta,0) - L(|eta|) = eta/2 - M(eta): sum(eta) is linear in Theta (colsum . theta, added by the update
     // kernel), so only M(eta) = |eta|/2 + L(|eta|) is accumulated here
     double4_t acc2[2][NC];        // ping-pong accumulators: tile tt uses acc2[tt & 1]
-    SoftplusRec pend[NP];         // table records of the pending values (an all-zero record evaluates to 0)
+    SoftplusRec pend[NP > 0 ? NP : 1];   // table records of the pending values (an all-zero record evaluates to 0)
 
     // a[]: this lane's X fragments of the tile about to be multiplied; tile_block refills each group's registers with
     // the NEXT tile's fragments (nx: this lane's column of it in global memory) as soon as the group has been issued,
     // so a load has NG-1 groups (about 1.6 us at d = 64) to arrive.  accN: accumulators of this tile (on entry they
     // still hold the tile before last, whose pending values cluster 0 evaluates).  accO: the finished previous tile.
-    double a[KS];
+    double a[AR];
     // k-steps [k0, k1) of a tile (colp: the tile's first double, uniform; each lane adds its 16-byte slot last, so the
     // address is scalar base + lane offset): 16-byte loads of the pairs the range covers whole, 8-byte loads at odd ends
     const int lane2 = lane * 2;
@@ -198,16 +203,17 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
             const double *q = colp + kp * 128;
             if (lo && hi) {
                 const double2 p = *(const double2 *)(q + lane2);
-                a[2 * kp] = p.x;
-                a[2 * kp + 1] = p.y;
+                a[(2 * kp) % AR] = p.x;
+                a[(2 * kp + 1) % AR] = p.y;
             } else if (lo) {
-                a[2 * kp] = q[lane2];
+                a[(2 * kp) % AR] = q[lane2];
             } else if (hi) {
-                a[2 * kp + 1] = q[lane2 + 1];
+                a[(2 * kp + 1) % AR] = q[lane2 + 1];
             }
         }
     };
-    auto tile_block = [&](const double *__restrict__ nx, double4_t *accN, const double4_t *accO, auto have_old) {
+    // cx / nx: this tile and the next one in global memory (the ring's refills reach into both)
+    auto tile_block = [&](const double *__restrict__ cx, const double *__restrict__ nx, double4_t *accN, const double4_t *accO, auto have_old) {
         constexpr bool OLD = decltype(have_old)::value;
         uint32_t addr[NV];
         SoftplusRec rec[NV];
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         auto mfma_ks = [&](int ks) {
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
+                accN[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks % AR], b[ks][c], ks == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : accN[c], 0, 0, 0);
         };
 #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -249,7 +255,11 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
 #pragma unroll
             for (int ks = g * GK + 1; ks < (g + 1) * GK && ks < KS; ks++) mfma_ks(ks);
             __builtin_amdgcn_sched_barrier(0);
-            refill(nx, g * GK, (g + 1) * GK < KS ? (g + 1) * GK : KS);
+            {   // the registers of group g are free: they take group g + LEAD (of this tile, or of the next one)
+                constexpr int NGc = NG;
+                const int gl = (g + LEAD) % NGc;
+                refill(g + LEAD < NGc ? cx : nx, gl * GK, (gl + 1) * GK < KS ? (gl + 1) * GK : KS);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -286,15 +296,15 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         // memory), so only the first unit waits for its first fragments
         const int lim = u + 1 < u_end ? nt : nt - 1;
         auto col = [&](int i) { return x0 + (size_t)(i < lim ? i : lim) * (KS * 64); };
-        if (u == u_begin) refill(col(0), 0, KS);
-        tile_block(col(1), acc2[0], acc2[1], first_tile);
+        if (u == u_begin) refill(col(0), 0, AR);
+        tile_block(col(0), col(1), acc2[0], acc2[1], first_tile);
         int i = 1;
         for (; i + 1 < nt; i += 2) {
-            tile_block(col(i + 1), acc2[1], acc2[0], with_old);
-            tile_block(col(i + 2), acc2[0], acc2[1], with_old);
+            tile_block(col(i), col(i + 1), acc2[1], acc2[0], with_old);
+            tile_block(col(i + 1), col(i + 2), acc2[0], acc2[1], with_old);
         }
         if (i < nt) {
-            tile_block(col(i + 1), acc2[1], acc2[0], with_old);
+            tile_block(col(i), col(i + 1), acc2[1], acc2[0], with_old);
             drain(acc2[1], acc2[0]);
         } else {
             drain(acc2[0], acc2[1]);
@@ -472,9 +482,9 @@ static MfmaPlan make_plan(const mcmchip_target *t, long nchain, int num_cu)
 {
     MfmaPlan pl;
     pl.ks = t->ksteps;
-    pl.nc = MFMA_NC;
+    pl.nc = pl.ks > 32 ? 1 : MFMA_NC;        // d > 128: one 16-chain tile per wave (its Theta fragments are 128 registers)
     const int tc = mfma_tc(pl.ks);
-    long per_wg = 16L * MFMA_NC * MFMA_NW;
+    long per_wg = 16L * pl.nc * MFMA_NW;
     pl.chain_blocks = (nchain + per_wg - 1) / per_wg;
     pl.ldc = pl.chain_blocks * per_wg;
     // units: at most 256 per target, at least two tile granules each (table load and B preload of a workgroup cost a
@@ -506,8 +516,9 @@ template <int KS, int TC>
 static void launch_ld(const MfmaPlan &pl, const mcmchip_target *t, const double *prop, double *partial,
                       DeviceCtx *dc)
 {
+    constexpr int NC = KS > 32 ? 1 : MFMA_NC;
     dim3 grid((unsigned)pl.chain_blocks, (unsigned)pl.nsplit), block(MFMA_NW * 64);
-    hipLaunchKernelGGL((logdens_mfma_kernel<KS, MFMA_NC, MFMA_NW, TC>), grid, block, 0, dc->stream, t->xt, prop,
+    hipLaunchKernelGGL((logdens_mfma_kernel<KS, NC, MFMA_NW, TC>), grid, block, 0, dc->stream, t->xt, prop,
                        pl.ldc, partial, pl.tiles_per_unit, pl.units_per_split, pl.nunits, t->ntiles, dc->d_tables);
 }
 
@@ -527,6 +538,8 @@ static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const dou
     case 24: launch_ld<24, 1>(pl, t, prop, partial, dc); break;
     case 28: launch_ld<28, 1>(pl, t, prop, partial, dc); break;
     case 32: launch_ld<32, 1>(pl, t, prop, partial, dc); break;
+    case 48: launch_ld<48, 1>(pl, t, prop, partial, dc); break;
+    case 64: launch_ld<64, 1>(pl, t, prop, partial, dc); break;
     default: return set_error(MCMCHIP_EINVAL, "MFMA path supports d <= %d", MCMCHIP_MFMA_MAXD);
     }
     HIP_TRY(hipGetLastError());

@@ -234,7 +234,9 @@ def _synthetic(n, d, seed=42):
 @pytest.mark.parametrize("n,d,C", [(20000, 64, 256), (5003, 5, 100), (8192, 20, 300), (4099, 33, 64),
                                    (6007, 65, 70), (4099, 100, 64), (8192, 128, 300), (33, 96, 5),    # d > 64: one tile per chunk
                                    (5000, 32, 64), (3000, 48, 70), (3000, 56, 70), (7, 100, 3), (17, 70, 3),
-                                   (300000, 64, 40)])                # several units per workgroup
+                                   (300000, 64, 40),                 # several units per workgroup
+                                   (4099, 129, 40), (8192, 192, 130), (6007, 200, 64), (8192, 256, 300), (9, 250, 3),
+                                   (60000, 256, 129)])               # d > 128: ring of fragment registers, 16 chains a wave
 def test_logdens_mfma_vs_oracle(api, oracle_mod, n, d, C):
     X, y, beta = _synthetic(n, d, seed=n)
     states = beta + 0.3 * np.random.default_rng(1).standard_normal((C, d))
@@ -247,7 +249,7 @@ def test_logdens_mfma_vs_oracle(api, oracle_mod, n, d, C):
 
 
 @pytest.mark.parametrize("scale_kind", ["scalar", "matrix"])
-@pytest.mark.parametrize("d", [16, 80])
+@pytest.mark.parametrize("d", [16, 80, 200])
 def test_metrop_mfma_injected_vs_oracle(api, oracle_mod, scale_kind, d):
     n, C, nbatch, blen, nspac = 8192, 128, 6, 3, 2
     niter = nbatch * blen * nspac
@@ -255,7 +257,7 @@ def test_metrop_mfma_injected_vs_oracle(api, oracle_mod, scale_kind, d):
     rng = np.random.default_rng(2)
     init = beta + 0.01 * rng.standard_normal((C, d))
     z, u = rng.standard_normal((C, niter, d)), rng.random((C, niter))
-    s0 = 0.02 if d == 16 else 0.008
+    s0 = {16: 0.02, 80: 0.008, 200: 0.004}[d]
     scale = s0 if scale_kind == "scalar" else s0 * np.linalg.cholesky(np.eye(d) + 0.3)
     ref = oracle_mod.metrop(oracle_mod.Target(abi.T_LOGISTIC, d, x=X, y=y, prior_c=0.125), init, nbatch, blen, nspac,
                             scale=scale, z=z, u=u, outfun="moments2", nthreads=16)

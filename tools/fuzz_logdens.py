@@ -18,7 +18,7 @@ def main():
     api.init(0)
     worst = 0.0
     for it in range(ncases):
-        d = int(rng.integers(1, 129))
+        d = int(rng.integers(1, 257))
         n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 3000), rng.integers(3000, 60000)]))
         C = int(rng.choice([rng.integers(1, 20), rng.integers(20, 700)]))
         X = rng.standard_normal((n, d))
