@@ -5,7 +5,7 @@ set -e
 out=$GRAFT_REPO_ROOT/${1:-gpurun_out/benchprof}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/stats -o b --output-format csv -- $B > $out/stats.log 2> $out/stats.err
 timeout -s KILL 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o b --output-format csv -- $B > $out/fetch.log 2> $out/fetch.err
 timeout -s KILL 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o b --output-format csv -- $B > $out/write.log 2> $out/write.err
