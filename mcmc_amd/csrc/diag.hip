@@ -217,46 +217,7 @@ __global__ void olbm_finish_kernel(const double *__restrict__ partial, long nseg
 // that is exactly 17 tiles on each of the 8 waves.  The columns of the first F/2+1 fragments are stored
 // a second time after column 16F, so (f+delta) never wraps: every fragment a wave needs in a k-step sits
 // at (one base register) + (compile-time offset) and a k-step costs NB + F/2 ds_read_b64 for its MFMAs.
-#define OM_SLAB 16
-#define OM_NW 8
-#define OL_ONEPASS_MIN_N (1L << 20)      // shorter series: the means come from colsum_kernel first, as in olbm.c:38-43
-#define OL_PILOT_RUNS 4096               // runs of 8 rows in the provisional centre's sample
-#define OL_ONEPASS_MAX_LOSS 1.0e3        // repeat about the exact mean if the correction would cost more than 3 digits
-
-typedef double om_double4 __attribute__((ext_vector_type(4)));
-
-template <int F> struct OmShape {
-    static constexpr int NB = F >= 8 ? F / 8 : 1;       // base fragments per wave
-    static constexpr int NACT = F / NB;                 // waves that own tiles (8, or 4 at F = 4)
-    static constexpr int H = F / 2;
-    static constexpr int NS = NB * H + 1;               // accumulator tiles per wave (last = the delta = H tile)
-    static constexpr int NFR = NB + H;                  // fragments read per k-step
-    static constexpr int PP = F * 16;
-    static constexpr int DUPC = (H + 1) * 16;           // columns stored twice
-    // LD = 2 mod 4: the two fragment rows a 32-lane ds_read_b64 group touches are 8 rows = 32 banks apart
-    // (conflict-free); the transposed ds_write_b64 of the producer is 2-way, off the critical path
-    static constexpr int LD = PP + DUPC + 2;
-    static constexpr int NLD = PP / (4 * OM_NW);        // 4-column load slots of a wave per slab
-    static constexpr int CW = PP / OM_NW;               // columns a wave produces (contiguous): 8, 16, 32
-    static constexpr int NPART = 64 / CW;               // a column's 16 windows are summed by NPART lanes ...
-    static constexpr int WPP = OM_SLAB / NPART;         // ... WPP consecutive windows each
-    // per-wave image of the differences x[t+len] - x[t], [column][window]; 18 doubles = 144 B per column: the 16-byte
-    // reads of 8 consecutive lanes (columns) fall in 8 disjoint bank groups
-    static constexpr int DLD = OM_SLAB + 2;
-    // the delta = H tile of wave w: base index and whether the wave has one
-    __host__ __device__ static constexpr int extra_base(int w) { return NB == 2 ? (w < NACT / 2 ? 0 : 1) : 0; }
-    __host__ __device__ static constexpr bool has_extra(int w) { return NB == 2 ? true : w < NACT / 2; }
-    static constexpr size_t lds_bytes = ((size_t)2 * OM_SLAB * LD + PP + (size_t)PP * DLD) * 8;
-};
-
-// row_shr:N within the 16 lanes of a DPP row, zero fill
-template <int N> __device__ __forceinline__ double om_row_shr(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
+#include "olbm_shape.h"
 
 template <int F>
 __global__ __launch_bounds__(64 * OM_NW) void olbm_mfma_kernel(const double *__restrict__ x, long n, int p, long len,
@@ -682,10 +643,32 @@ static int launch_olbm_mfma(const double *x, long n, int p, long len, long nwin,
     return MCMCHIP_OK;
 }
 
+int olbm_pilot_centre(const double *x, long n, int p, double *dcentre, hipStream_t s)
+{
+    hipLaunchKernelGGL(pilot_centre_kernel, dim3((unsigned)p), dim3(256), 0, s, x, n, OL_PILOT_RUNS, dcentre);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
+int olbm_exact_means(const double *x, long n, int p, double *dmean, hipStream_t s)
+{
+    const long chunk = 1 << 20;
+    const long nchunk = (n + chunk - 1) / chunk;
+    DevBuf cpart;
+    HIP_TRY(cpart.alloc((size_t)p * nchunk * 8));
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nchunk, (unsigned)p), dim3(256), 0, s, x, n, chunk, nchunk, cpart.as<double>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)((p + 63) / 64)), dim3(64), 0, s, cpart.as<double>(), nchunk, n, p, dmean);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));       // cpart is released on return
+    return MCMCHIP_OK;
+}
+
 int run_olbm(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc)
 {
     hipStream_t s = dc->stream;
     if (n >= (1L << 31)) return set_error(MCMCHIP_EINVAL, "olbm: n exceeds the reference's int range (olbm.c:25)");
+    if (olbm_comb_applies(n, p, len)) return run_olbm_comb(x, n, p, len, mean, var, nocalc, dc);   // long windows: olbm_comb.hip
     DevBuf dmean, dvar, part, cpart, dcentre, ddelta;
     HIP_TRY(dmean.alloc((size_t)p * 8));
     HIP_TRY(dvar.alloc((size_t)p * p * 8));

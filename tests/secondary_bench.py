@@ -186,7 +186,7 @@ def c5(n=4_000_000, p=32, blens=(1000,)):
     return res
 
 
-def c5dev(n=100_000_000, p=256, blen=10000):
+def c5dev(n=100_000_000, p=256, blen=10000, do_initseq=True):
     """BASELINE.json config 5 at full size: p AR(1) columns of n steps generated ON THE DEVICE (column-major
     n x p, 204.8 GB at the defaults), rho_j = 0.5 + 0.49 j/(p-1).  Generation: blocks of 512 steps by a scaled
     cumulative sum, carries from the two preceding blocks (rho^1024 < 4e-5: the rest is dropped)."""
@@ -222,19 +222,20 @@ def c5dev(n=100_000_000, p=256, blen=10000):
     g0, vp, vd, vc = (np.empty(p) for _ in range(4))
     Gp, Gd, Gc = (np.empty((p, cap)) for _ in range(3))
     t0 = time.perf_counter()
-    rc = L.mcmchip_initseq(x.data_ptr(), n, p, 1, cap, n_out.ctypes.data, g0.ctypes.data, Gp.ctypes.data,
+    rc = 0 if not do_initseq else L.mcmchip_initseq(x.data_ptr(), n, p, 1, cap, n_out.ctypes.data, g0.ctypes.data, Gp.ctypes.data,
                            Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data, vd.ctypes.data, vc.ctypes.data)
     el = time.perf_counter() - t0
     assert rc == 0, L.mcmchip_last_error()
     kn, kms, klaunch = api.last_kernel_time()
     lags = 2 * n_out
-    res.append({"config": "C5 initseq n=%d p=%d (generated on device, %.1f s)" % (n, p, gen_s), "seconds": el,
-                "kernel": kn, "kernel_ms_avg": kms, "kernel_launches": klaunch, "max_lag_pairs": int(n_out.max()),
-                "mean_lag_pairs": float(n_out.mean()),
-                "useful_lag_products_per_s": float((lags * n).sum() / el),
-                "useful_TFLOPs": float(2.0 * (lags * n).sum() / el / 1e12),
-                "var_con_over_gamma0": [float(v) for v in (vc / g0)[[0, p // 2, p - 1]]],
-                "theory_(1+rho)/(1-rho)": [(1 + r) / (1 - r) for r in (0.5, 0.5 + 0.49 * (p // 2) / max(p - 1, 1), 0.99)]})
+    if do_initseq:
+        res.append({"config": "C5 initseq n=%d p=%d (generated on device, %.1f s)" % (n, p, gen_s), "seconds": el,
+                    "kernel": kn, "kernel_ms_avg": kms, "kernel_launches": klaunch, "max_lag_pairs": int(n_out.max()),
+                    "mean_lag_pairs": float(n_out.mean()),
+                    "useful_lag_products_per_s": float((lags * n).sum() / el),
+                    "useful_TFLOPs": float(2.0 * (lags * n).sum() / el / 1e12),
+                    "var_con_over_gamma0": [float(v) for v in (vc / g0)[[0, p // 2, p - 1]]],
+                    "theory_(1+rho)/(1-rho)": [(1 + r) / (1 - r) for r in (0.5, 0.5 + 0.49 * (p // 2) / max(p - 1, 1), 0.99)]})
     mean = np.zeros(p)
     var = np.empty((p, p))
     for nocalc in (0, 1):
@@ -260,6 +261,8 @@ if __name__ == "__main__":
         if w.startswith("c5dev"):          # c5dev or c5dev=n,p,len
             a = [int(v) for v in w[6:].split(",")] if "=" in w else []
             r = c5dev(*a)
+        elif w.startswith("c5olbm="):        # c5olbm=n,p,len: the olbm half of c5dev alone
+            r = c5dev(*[int(v) for v in w[7:].split(",")], do_initseq=False)
         elif w.startswith("c5="):            # c5=n,p,len[,len...]
             a = [int(v) for v in w[3:].split(",")]
             r = c5(a[0], a[1], tuple(a[2:]))

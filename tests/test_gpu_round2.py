@@ -825,6 +825,47 @@ def test_time_sharded_initseq_and_olbm_device_route(api, oracle_mod):
     assert np.max(np.abs(v1 - ref)) <= 1e-10 * np.max(np.abs(ref)) and np.allclose(m1, mean, rtol=1e-13)
 
 
+@pytest.mark.parametrize("n,p,blen", [(40_000, 3, 1024), (150_000, 200, 5000), (66_000, 256, 1027), (1_200_000, 17, 3000),
+                                       (30_000, 64, 1500), (50_000, 129, 2048), (13_000, 256, 4000), (3_100_000, 2, 1_000_000)])
+def test_olbm_comb_route_vs_oracle(api, oracle_mod, n, p, blen):
+    """Windows of >= 1024 rows take olbm_comb.hip (x read once: teeth one window length apart swept together, window sums
+    relative to the start of each piece on the matrix cores, pieces chained and rank-two terms added afterwards, exact
+    means out of the chain).  Against the oracle at 1e-10 with the means supplied (the R front end's default) and
+    computed by the call, and against an 80-bit evaluation of the definition at 1e-12; shapes with ragged last steps
+    (len not a multiple of 16), a remainder tooth, fewer teeth than a comb holds, one and several workgroups."""
+    import math
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(n % 1000 + p)
+    x = np.empty((n, p))
+    for c in range(p):
+        x[:, c] = lfilter([1.0], [1.0, -(0.1 + 0.85 * c / p)], rng.standard_normal(n)) + (3.0 + 50.0 * (c % 3))
+    if p >= 2:
+        x[:, 1] += np.linspace(-5.0, 5.0, n)
+    ref, refmean = oracle_mod.olbm(x, blen)
+    sc = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    tol = 1e-10 if blen <= 10_000 and 4 * blen <= n else 1e-9     # what olbm.c's own arithmetic is good for (see the one-pass test)
+    got = api.olbm(x, blen)                          # means supplied
+    assert np.all(np.abs(got - ref) <= tol * sc)
+    assert np.array_equal(got, got.T)
+    got2 = api.olbm(x, blen, demean=False)           # means computed by the call
+    assert np.all(np.abs(got2 - ref) <= tol * sc)
+    assert np.array_equal(got2, got2.T)
+    k = min(p, 4)
+    exact = np.array([math.fsum(x[:, c]) / n for c in range(k)])
+    xl = x[:, :k].astype(np.longdouble) - exact.astype(np.longdouble)
+    cs = np.vstack([np.zeros((1, k), dtype=np.longdouble), np.cumsum(xl, axis=0)])
+    V = cs[blen:] - cs[:-blen]
+    true = np.asarray((V.T @ V) / (np.longdouble(n - blen + 1) * n * blen), dtype=np.float64)
+    st = np.sqrt(np.outer(np.diag(true), np.diag(true)))
+    assert np.all(np.abs(got2[:k, :k] - true) <= 1e-12 * st)
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x.T)).to("cuda:0")
+    v3, m3 = api.olbm_device(xd, blen)
+    assert np.array_equal(v3, got2)
+    assert np.all(np.abs(m3[:k] - exact) <= 1e-14 * np.abs(exact))
+    assert api.last_kernel_time()[0] == "olbm_comb_kernel"
+
+
 @pytest.mark.parametrize("n,p,blen", [(1_200_000, 5, 1000), (1_048_576, 70, 64), (1_100_003, 3, 1), (1_300_000, 130, 4097),
                                        (1_050_000, 2, 525_000), (1_048_581, 2, 1_048_581)])
 def test_olbm_one_pass_route_vs_oracle(api, oracle_mod, n, p, blen):
