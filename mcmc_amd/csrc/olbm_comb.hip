@@ -579,7 +579,8 @@ bool olbm_comb_applies(long n, int p, long len)
 
 // what a finish step needs from the walk (kept so that the finish can be repeated about another centre)
 struct OlbmCombState {
-    DevBuf part, pd, pe, small, corr, plan;
+    DevBuf all;
+    double *part = nullptr, *pd = nullptr, *pe = nullptr, *small = nullptr, *corr = nullptr;
     long nseg = 0;
     int np = 0, nchunk = 0, nsplit = 0, per_split = 0;
     int *dpcnt = nullptr;
@@ -597,19 +598,19 @@ static int finish_olbm_comb(const double *x, long n, int p, long len, const doub
     OlbmCombState &K = *keep;
     const long nwin = n - len + 1, ntile = n / len;
     const int ntiles = S::NACT * S::NS;
-    double *csum = K.small.as<double>(), *tsum = csum + (size_t)K.nchunk * S::PP, *s0 = tsum + (size_t)K.nchunk * S::PP,
+    double *csum = K.small, *tsum = csum + (size_t)K.nchunk * S::PP, *s0 = tsum + (size_t)K.nchunk * S::PP,
            *tail = s0 + S::PP, *shift = tail + S::PP;
     hipLaunchKernelGGL(olbm_s0_kernel, dim3((unsigned)p), dim3(256), 0, s, x, n, len, ntile, dcentre, s0, tail);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(olbm_chain_mean_kernel, dim3(1), dim3(256), 0, s, tsum, K.nchunk, S::PP, p, s0, tail, dcentre, n, len,
                        ntile, dmean_out ? 1 : 0, dmean_out, ddelta, shift);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(olbm_comb_corr_kernel<F>, dim3((unsigned)ntiles, (unsigned)K.nsplit), dim3(256), 0, s, K.pe.as<double>(),
-                       K.pd.as<double>(), K.dpcnt, K.np, K.per_split, shift, K.corr.as<double>());
+    hipLaunchKernelGGL(olbm_comb_corr_kernel<F>, dim3((unsigned)ntiles, (unsigned)K.nsplit), dim3(256), 0, s, K.pe,
+                       K.pd, K.dpcnt, K.np, K.per_split, shift, K.corr);
     HIP_TRY(hipGetLastError());
     const double denom = (double)nwin * (double)n * (double)len;
-    hipLaunchKernelGGL(olbm_comb_finish_kernel<F>, dim3((unsigned)ntiles), dim3(256), 0, s, K.part.as<double>(), K.nseg,
-                       K.corr.as<double>(), K.nsplit, p, denom, dvar);
+    hipLaunchKernelGGL(olbm_comb_finish_kernel<F>, dim3((unsigned)ntiles), dim3(256), 0, s, K.part, K.nseg,
+                       K.corr, K.nsplit, p, denom, dvar);
     HIP_TRY(hipGetLastError());
     return MCMCHIP_OK;
 }
@@ -646,25 +647,34 @@ static int launch_olbm_comb(const double *x, long n, int p, long len, const doub
     const int per_split = (np + nsplit - 1) / nsplit;
     nsplit = (np + per_split - 1) / per_split;
 
+    // one allocation (carved on 256-byte boundaries) and one upload for the plan: a call is short enough for ten
+    // hipMalloc / hipFree pairs and five copies to show
     OlbmCombState &K = *keep;
-    HIP_TRY(K.part.alloc((size_t)nseg * S::NACT * S::NS * 256 * 8));
-    HIP_TRY(K.pd.alloc((size_t)np * S::PP * 8));
-    HIP_TRY(K.pe.alloc((size_t)np * S::PP * 8));
-    HIP_TRY(K.small.alloc(((size_t)2 * nchunk + 4) * S::PP * 8));
-    HIP_TRY(K.corr.alloc((size_t)nsplit * ntiles * 256 * 8));
-    HIP_TRY(K.plan.alloc(pl.combs.size() * sizeof(OlbmComb) + ((size_t)pl.first.size() + pl.steps.size() + np) * 4 + (size_t)np + 64));
-    char *pb = K.plan.as<char>();
-    OlbmComb *dcombs = (OlbmComb *)pb;
-    int *dfirst = (int *)(pb + pl.combs.size() * sizeof(OlbmComb));
-    int *dsteps = dfirst + pl.first.size();
-    int *dpcnt = dsteps + pl.steps.size();
-    unsigned char *dptile = (unsigned char *)(dpcnt + np);
-    HIP_TRY(hipMemcpyAsync(dcombs, pl.combs.data(), pl.combs.size() * sizeof(OlbmComb), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dfirst, pl.first.data(), pl.first.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dsteps, pl.steps.data(), pl.steps.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dpcnt, pl.pcnt.data(), (size_t)np * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dptile, pl.ptile.data(), (size_t)np, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));                       // the plan's host vectors go out of scope
+    const size_t sz_part = (size_t)nseg * S::NACT * S::NS * 256 * 8, sz_piece = (size_t)np * S::PP * 8,
+                 sz_small = ((size_t)2 * nchunk + 4) * S::PP * 8, sz_corr = (size_t)nsplit * ntiles * 256 * 8;
+    const size_t o_combs = 0, o_first = o_combs + pl.combs.size() * sizeof(OlbmComb), o_steps = o_first + pl.first.size() * 4,
+                 o_pcnt = o_steps + pl.steps.size() * 4, o_ptile = o_pcnt + (size_t)np * 4, sz_plan = o_ptile + (size_t)np;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    HIP_TRY(K.all.alloc(up(sz_part) + 2 * up(sz_piece) + up(sz_small) + up(sz_corr) + up(sz_plan)));
+    char *cursor = K.all.as<char>();
+    auto carve = [&](size_t bytes) { char *r = cursor; cursor += up(bytes); return r; };
+    K.part = (double *)carve(sz_part);
+    K.pd = (double *)carve(sz_piece);
+    K.pe = (double *)carve(sz_piece);
+    K.small = (double *)carve(sz_small);
+    K.corr = (double *)carve(sz_corr);
+    char *pb = carve(sz_plan);
+    std::vector<char> hplan(sz_plan);
+    memcpy(hplan.data() + o_combs, pl.combs.data(), pl.combs.size() * sizeof(OlbmComb));
+    memcpy(hplan.data() + o_first, pl.first.data(), pl.first.size() * 4);
+    memcpy(hplan.data() + o_steps, pl.steps.data(), pl.steps.size() * 4);
+    memcpy(hplan.data() + o_pcnt, pl.pcnt.data(), (size_t)np * 4);
+    memcpy(hplan.data() + o_ptile, pl.ptile.data(), (size_t)np);
+    HIP_TRY(hipMemcpyAsync(pb, hplan.data(), sz_plan, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                       // hplan goes out of scope
+    OlbmComb *dcombs = (OlbmComb *)(pb + o_combs);
+    int *dfirst = (int *)(pb + o_first), *dsteps = (int *)(pb + o_steps), *dpcnt = (int *)(pb + o_pcnt);
+    unsigned char *dptile = (unsigned char *)(pb + o_ptile);
     K.nseg = nseg;
     K.np = np;
     K.nchunk = nchunk;
@@ -676,14 +686,14 @@ static int launch_olbm_comb(const double *x, long n, int p, long len, const doub
     timing_reset("olbm_comb_kernel");
     timing_begin(s);
     hipLaunchKernelGGL(kern, dim3((unsigned)nseg), dim3(64 * OM_NW), C::lds_bytes, s, x, n, p, len, dcombs, dfirst, dsteps,
-                       K.part.as<double>(), K.pd.as<double>(), K.pe.as<double>(), exper);
+                       K.part, K.pd, K.pe, exper);
     timing_end(s);
     HIP_TRY(hipGetLastError());
     // e_j -> E_j in place (once: a repeat of the finish about another centre reuses them)
-    double *csum = K.small.as<double>(), *tsum = csum + (size_t)nchunk * S::PP;
-    hipLaunchKernelGGL(olbm_chain_sum_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, K.pe.as<double>(), np, S::PP, csum);
+    double *csum = K.small, *tsum = csum + (size_t)nchunk * S::PP;
+    hipLaunchKernelGGL(olbm_chain_sum_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, K.pe, np, S::PP, csum);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(olbm_chain_prefix_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, K.pe.as<double>(), dptile, np, S::PP,
+    hipLaunchKernelGGL(olbm_chain_prefix_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, K.pe, dptile, np, S::PP,
                        csum, tsum);
     HIP_TRY(hipGetLastError());
     return finish_olbm_comb<F>(x, n, p, len, dcentre, dmean_out, ddelta, dvar, dc, keep);
@@ -692,33 +702,31 @@ static int launch_olbm_comb(const double *x, long n, int p, long len, const doub
 int run_olbm_comb(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc)
 {
     hipStream_t s = dc->stream;
-    DevBuf dmean, dvar, dcentre, ddelta;
-    HIP_TRY(dmean.alloc((size_t)p * 8));
-    HIP_TRY(dvar.alloc((size_t)p * p * 8));
-    HIP_TRY(dcentre.alloc((size_t)p * 8));
-    HIP_TRY(ddelta.alloc((size_t)p * 8));
+    DevBuf vecs;                                              // var | mean | centre | delta
+    HIP_TRY(vecs.alloc(((size_t)p * p + 3 * (size_t)p) * 8));
+    double *dvar = vecs.as<double>(), *dmean = dvar + (size_t)p * p, *dcentre = dmean + p, *ddelta = dcentre + p;
     // means not supplied: a long series gets them out of the chain (about a sampled centre), a short one from a pass
     // of its own, as in olbm.c:38-43
     const bool one_pass = !nocalc && n >= OL_ONEPASS_MIN_N;
-    if (nocalc) HIP_TRY(hipMemcpyAsync(dmean.p, mean, (size_t)p * 8, hipMemcpyHostToDevice, s));
-    else if (one_pass) { if (int rc = olbm_pilot_centre(x, n, p, dcentre.as<double>(), s)) return rc; }
-    else if (int rc = olbm_exact_means(x, n, p, dmean.as<double>(), s)) return rc;
+    if (nocalc) HIP_TRY(hipMemcpyAsync(dmean, mean, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    else if (one_pass) { if (int rc = olbm_pilot_centre(x, n, p, dcentre, s)) return rc; }
+    else if (int rc = olbm_exact_means(x, n, p, dmean, s)) return rc;
     OlbmCombState K;
-    const double *centre = one_pass ? dcentre.as<double>() : dmean.as<double>();
-    double *mean_out = one_pass ? dmean.as<double>() : nullptr;
+    const double *centre = one_pass ? dcentre : dmean;
+    double *mean_out = one_pass ? dmean : nullptr;
     int rc;
-    if (p <= 64) rc = launch_olbm_comb<4>(x, n, p, len, centre, mean_out, ddelta.as<double>(), dvar.as<double>(), dc, &K);
-    else if (p <= 128) rc = launch_olbm_comb<8>(x, n, p, len, centre, mean_out, ddelta.as<double>(), dvar.as<double>(), dc, &K);
-    else rc = launch_olbm_comb<16>(x, n, p, len, centre, mean_out, ddelta.as<double>(), dvar.as<double>(), dc, &K);
+    if (p <= 64) rc = launch_olbm_comb<4>(x, n, p, len, centre, mean_out, ddelta, dvar, dc, &K);
+    else if (p <= 128) rc = launch_olbm_comb<8>(x, n, p, len, centre, mean_out, ddelta, dvar, dc, &K);
+    else rc = launch_olbm_comb<16>(x, n, p, len, centre, mean_out, ddelta, dvar, dc, &K);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(var, dvar.p, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
-    if (!nocalc) HIP_TRY(hipMemcpyAsync(mean, dmean.p, (size_t)p * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
+    if (!nocalc) HIP_TRY(hipMemcpyAsync(mean, dmean, (size_t)p * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (one_pass) {
         // the sampled centre enters only through s0 - len * delta (the matrix-core sums involve no centre): digits lost
         // there, 1 + len delta_c^2 / (n var_cc), worst column; beyond three the finish is repeated about the exact mean
         std::vector<double> hd((size_t)p);
-        HIP_TRY(hipMemcpy(hd.data(), ddelta.p, (size_t)p * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hd.data(), ddelta, (size_t)p * 8, hipMemcpyDeviceToHost));
         bool redo = false;
         for (int c = 0; c < p; c++) {
             const double main_term = var[c + (size_t)p * c] * (double)n;
@@ -726,11 +734,11 @@ int run_olbm_comb(const double *x, long n, int p, long len, double *mean, double
             if (!(corr <= OL_ONEPASS_MAX_LOSS * main_term) && !(fabs(hd[c]) <= 1e-14 * fabs(mean[c]))) redo = true;
         }
         if (redo) {
-            if (p <= 64) rc = finish_olbm_comb<4>(x, n, p, len, dmean.as<double>(), nullptr, nullptr, dvar.as<double>(), dc, &K);
-            else if (p <= 128) rc = finish_olbm_comb<8>(x, n, p, len, dmean.as<double>(), nullptr, nullptr, dvar.as<double>(), dc, &K);
-            else rc = finish_olbm_comb<16>(x, n, p, len, dmean.as<double>(), nullptr, nullptr, dvar.as<double>(), dc, &K);
+            if (p <= 64) rc = finish_olbm_comb<4>(x, n, p, len, dmean, nullptr, nullptr, dvar, dc, &K);
+            else if (p <= 128) rc = finish_olbm_comb<8>(x, n, p, len, dmean, nullptr, nullptr, dvar, dc, &K);
+            else rc = finish_olbm_comb<16>(x, n, p, len, dmean, nullptr, nullptr, dvar, dc, &K);
             if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(var, dvar.p, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
     }
