@@ -344,7 +344,15 @@ int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean);
  * double *var, int *nocalcin) (mcmc.h:16-17, olbm.c:22-78).  x is n x p column-major.
  * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned (for n >= 2^20 and p <= 256
  * in the same pass over x as the matrix, not in a pass of their own as in olbm.c:38-43; they come out correctly
- * rounded to an ulp, where the reference's sequential sum is good to ~sqrt(n) ulp). */
+ * rounded to an ulp, where the reference's sequential sum is good to ~sqrt(n) ulp).
+ * Windows of >= 1024 rows (p <= 256, at least two window lengths of windows) are computed with x read once instead of
+ * twice (olbm_comb.hip; MCMCHIP_OLBM_COMB=0 keeps the two-stream kernel).
+ * Accuracy, stated here because it is a deviation a caller should know: the device agrees with an 80-bit evaluation
+ * of the definition to ~1e-14 of sqrt(var_ii var_jj).  olbm.c itself is not that good -- it adds the n terms of a mean
+ * one after the other and carries ONE running window sum through all n - len updates (olbm.c:38-43, 52-62) -- so the
+ * device is held to the reference's arithmetic (the oracle) at 1e-10 for len <= 10 000 and len <= n / 4, and at 1e-9 for
+ * longer windows, where olbm.c is ~1.4e-10 away from the 80-bit value itself (tools/olbm_conditioning.py,
+ * tests/test_gpu_round2.py::test_olbm_one_pass_route_vs_oracle, ::test_olbm_comb_route_vs_oracle). */
 int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
                  int32_t nocalc, int device_ptrs);
 
