@@ -294,7 +294,9 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             if ((desc_device_ptrs ? hipMemcpyAsync(t->x, desc->x, xb, kind, dc->stream)
                                   : copy_from_pageable_host(t->x, desc->x, xb, dc->stream)) != hipSuccess ||
                 hipMemcpyAsync(t->y, desc->y, yb, kind, dc->stream) != hipSuccess) { rc = set_error(MCMCHIP_EHIP, "copy of the design matrix failed"); break; }
-            if (desc->kind == MCMCHIP_T_LOGISTIC && desc->d <= MCMCHIP_MFMA_MAXD) {
+            // fp64 MFMA layout: the logistic posterior, and (for mcmchip_logdens) the model-selection posterior, whose
+            // masks are folded into the states; the binomial regression needs its totals first (below)
+            if ((desc->kind == MCMCHIP_T_LOGISTIC || desc->kind == MCMCHIP_T_LOGISTIC_MODELS) && desc->d <= MCMCHIP_MFMA_MAXD) {
                 rc = build_mfma_tiles(t, dc->stream);
                 if (rc) break;
             }
@@ -351,6 +353,10 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             if (k < 2 || desc->npar != 1 + k * desc->d + k + 1) { rc = set_error(MCMCHIP_EINVAL, "logistic-models descriptor: par must be k, k x d masks, k log pseudo-priors, constant"); break; }
         }
         if (desc->kind == MCMCHIP_T_BINOMIAL_LOGIT && desc->npar != desc->n) { rc = set_error(MCMCHIP_EINVAL, "binomial descriptor needs one total per row of x"); break; }
+        if (desc->kind == MCMCHIP_T_BINOMIAL_LOGIT && desc->d <= MCMCHIP_MFMA_MAXD && !desc->morph_flags) {
+            rc = build_mfma_tiles(t, dc->stream);      // row weights = the totals (par, in HBM by now)
+            if (rc) break;
+        }
         if (desc->kind == MCMCHIP_T_STUDENT_T && !(t->host_par[0] > 0)) { rc = set_error(MCMCHIP_EINVAL, "Student t descriptor needs df > 0"); break; }
         if (desc->morph_flags) {
             // morph() argument rules (R/morph.R:51,75-76)
@@ -384,6 +390,7 @@ void mcmchip_target_destroy(mcmchip_target *t)
     if (t->par) (void)hipFree(t->par);
     if (t->xt) (void)hipFree(t->xt);
     if (t->colsum) (void)hipFree(t->colsum);
+    if (t->wt) (void)hipFree(t->wt);
     if (t->morph_center) (void)hipFree(t->morph_center);
     delete t;
 }
@@ -451,6 +458,7 @@ int mcmchip_logdens_noalloc(const mcmchip_target *t, const double *states, int64
     if (!t || !states || !out || nchain <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_logdens_noalloc");
     if (int rc = check_target_device(t)) return rc;
     if (t->morph_flags) return set_error(MCMCHIP_EINVAL, "the MFMA path does not take a morphed descriptor");
+    if (is_temper_kind(t->kind)) return set_error(MCMCHIP_EINVAL, "mcmchip_logdens_noalloc takes metrop descriptors (use mcmchip_logdens)");
     return launch_logdens_mfma_noalloc(t, states, nchain, out, dc);
 }
 
@@ -517,7 +525,7 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
 
     bool mfma_ok = t->xt && !a->debug && !t->morph_flags;
     bool mfma = (a->path == MCMCHIP_PATH_MFMA) || (a->path == MCMCHIP_PATH_AUTO && mfma_ok && mfma_pays(t, nchain));
-    if (mfma && !mfma_ok) return set_error(MCMCHIP_EINVAL, "MFMA path needs a logistic descriptor with d <= %d and debug = FALSE", MCMCHIP_MFMA_MAXD);
+    if (mfma && !mfma_ok) return set_error(MCMCHIP_EINVAL, "MFMA path needs a logistic or binomial-regression descriptor with d <= %d, no morph and debug = FALSE", MCMCHIP_MFMA_MAXD);
 
     hipStream_t s = dc->stream;
     const int dp = a->device_ptrs;

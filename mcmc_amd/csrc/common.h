@@ -184,6 +184,7 @@ struct mcmchip_target {
     int64_t npad_rows = 0;  // zero rows appended (each contributes exactly -L(0) = -ln 2)
     double *xt = nullptr;
     double *colsum = nullptr;  // [dpad] column sums of the sign-folded X (sum_i eta_i = colsum . theta)
+    double *wt = nullptr;      // row weights, tile-major (MCMCHIP_T_BINOMIAL_LOGIT: the totals; null: unweighted)
     int device = 0;
     // copies in the HBM of other devices, made on demand by the *_multi entry points and released with the original
     std::vector<mcmchip_target *> replicas;

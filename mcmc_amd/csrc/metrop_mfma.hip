@@ -64,7 +64,7 @@ __global__ void tile_x_kernel(const double *__restrict__ x, const double *__rest
     double v = 0.0;
     if (row < n && col < d) {
         v = x[(size_t)row * d + col];
-        if (y[row] != 1.0) v = -v;
+        if (y && y[row] != 1.0) v = -v;
     }
     xt[idx] = v;
 }
@@ -92,11 +92,49 @@ __global__ __launch_bounds__(256) void tile_colsum_kernel(const double *__restri
     if (threadIdx.x == 0) colsum[col] = red[0];
 }
 
+// MCMCHIP_T_BINOMIAL_LOGIT (vignettes/morph.Rnw:361-365): sum(y * eta) - sum(w * log(1 + exp(eta))), w = par.  With
+// log(1 + e^eta) = eta/2 + M(eta), M(eta) = |eta|/2 + L(|eta|) (even in eta: no sign fold of X), the log density is
+//     sum_i (y_i - w_i/2) eta_i - sum_i w_i M(eta_i):
+// the first sum is linear in theta (colsum holds sum_i (2 y_i - w_i) X_ij, so that the update kernel's lin/2 is it), the
+// second is what the density kernel accumulates with the row weights as one more operand of the running sum's fma.
+// wt[tile][g][r] = w[16 tile + g + 4 r] (0 past n): the four rows lane group g = lane >> 4 holds in its accumulator
+// registers r = 0..3 are 32 contiguous bytes.
+__global__ void tile_w_kernel(const double *__restrict__ w, long n, long ntiles, double *__restrict__ wt)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ntiles * 16) return;
+    const long t = idx >> 4;
+    const int g = (int)((idx >> 2) & 3), r = (int)(idx & 3);
+    const long row = t * 16 + g + 4 * r;
+    wt[idx] = row < n ? w[row] : 0.0;
+}
+
+// one workgroup per column j: colsum[j] = sum_i (2 y_i - w_i) x[i][j], fixed-order reduction; padded columns 0
+__global__ __launch_bounds__(256) void weighted_colsum_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                               const double *__restrict__ w, long n, int d,
+                                                               double *__restrict__ colsum)
+{
+    __shared__ double red[256];
+    const int col = blockIdx.x;
+    double s = 0.0;
+    if (col < d)
+        for (long i = threadIdx.x; i < n; i += 256) s = fma(2.0 * y[i] - w[i], x[(size_t)i * d + col], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) colsum[col] = red[0];
+}
+
 int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
 {
+    const bool weighted = t->kind == MCMCHIP_T_BINOMIAL_LOGIT;
     // d > 64: k-steps in {20, 24, 28, 32}; d > 128: {48, 64} (whole turns of the kernel's 16-k-step fragment ring)
     t->dpad = t->d <= 64 ? ((t->d + 7) / 8) * 8 : (t->d <= 128 ? ((t->d + 15) / 16) * 16 : ((t->d + 63) / 64) * 64);
     if (t->dpad < 8) t->dpad = 8;
+    if (weighted && t->dpad == 128) t->dpad = 192;   // the weighted kernel has no registers to spare at 32 k-steps x 2 chain tiles
     t->ksteps = t->dpad / 4;
     long tiles = (t->n + 15) / 16;
     const int tc = mfma_tc(t->ksteps);
@@ -106,10 +144,19 @@ int build_mfma_tiles(mcmchip_target *t, hipStream_t s)
     size_t bytes = (size_t)tiles * t->ksteps * 64 * sizeof(double);
     HIP_TRY(hipMalloc((void **)&t->xt, bytes));
     long total = tiles * t->ksteps * 64;
-    hipLaunchKernelGGL(tile_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t->x, t->y,
-                       (long)t->n, t->d, t->ksteps, tiles, t->xt);
+    hipLaunchKernelGGL(tile_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t->x,
+                       weighted ? (const double *)nullptr : t->y, (long)t->n, t->d, t->ksteps, tiles, t->xt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMalloc((void **)&t->colsum, (size_t)t->dpad * sizeof(double)));
+    if (weighted) {
+        HIP_TRY(hipMalloc((void **)&t->wt, (size_t)tiles * 16 * sizeof(double)));
+        hipLaunchKernelGGL(tile_w_kernel, dim3((unsigned)((tiles * 16 + 255) / 256)), dim3(256), 0, s, t->par, (long)t->n, tiles, t->wt);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(weighted_colsum_kernel, dim3((unsigned)t->dpad), dim3(256), 0, s, t->x, t->y, t->par, (long)t->n, t->d, t->colsum);
+        HIP_TRY(hipGetLastError());
+        t->npad_rows = 0;            // rows of weight 0 contribute nothing
+        return MCMCHIP_OK;
+    }
     hipLaunchKernelGGL(tile_colsum_kernel, dim3((unsigned)t->dpad), dim3(256), 0, s, t->xt, t->ksteps, tiles, t->colsum);
     HIP_TRY(hipGetLastError());
     return MCMCHIP_OK;
@@ -141,12 +188,13 @@ template <int KS, int NC> struct TilePlan {
     }
 };
 
-template <int KS, int NC, int NW, int TC>
+template <int KS, int NC, int NW, int TC, bool W = false>
 __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__restrict__ xt,
                                                                const double *__restrict__ prop, long ldc,
                                                                double *__restrict__ partial,
                                                                int tiles_per_unit, int units_per_split, int nunits,
-                                                               long ntiles, const SoftplusTables *__restrict__ tab)
+                                                               long ntiles, const SoftplusTables *__restrict__ tab,
+                                                               const double *__restrict__ wt)
 {
     using P = TilePlan<KS, NC>;
     constexpr int GK = P::GK, NG = P::NG, NV = P::NV, NP = P::npend();
@@ -212,8 +260,22 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
             }
         }
     };
-    // cx / nx: this tile and the next one in global memory (the ring's refills reach into both)
-    auto tile_block = [&](const double *__restrict__ cx, const double *__restrict__ nx, double4_t *accN, const double4_t *accO, auto have_old) {
+    // W: the row weights of tile tt sit in w2[tt & 1], like its accumulators (register r <-> row (lane >> 4) + 4 r).  A
+    // tile's weights are loaded during its own block -- behind cluster 0, which still needs the array for the pending
+    // values of the tile before last -- and used in the next block and in cluster 0 of the one after.
+    double w2[2][4];
+    const int wlane = (lane >> 4) * 4;
+    auto load_w = [&](const double *__restrict__ wp, double *w) {
+        const double2 lo = *(const double2 *)(wp + wlane), hi = *(const double2 *)(wp + wlane + 2);
+        w[0] = lo.x; w[1] = lo.y; w[2] = hi.x; w[3] = hi.y;
+    };
+    auto add_w = [&](double &acc_sum, double wv, double m) {
+        if constexpr (W) acc_sum = fma(wv, m, acc_sum);
+        else acc_sum += m;
+    };
+    // cx / nx: this tile and the next one in global memory (the ring's refills reach into both); wx: this tile's weights
+    auto tile_block = [&](const double *__restrict__ cx, const double *__restrict__ nx, double4_t *accN, const double4_t *accO, auto have_old,
+                          const double *__restrict__ wx, double *wN, const double *wO) {
         constexpr bool OLD = decltype(have_old)::value;
         uint32_t addr[NV];
         SoftplusRec rec[NV];
@@ -232,8 +294,8 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
                 int ip = 0;
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    if (g == 0 && P::ad(v) == NG - 1) sum[v / 4] += softplus_lds_eval(accN[v / 4][v % 4], pend[ip++]);
-                    if (g > 0 && P::ad(v) == g - 1) sum[v / 4] += softplus_lds_eval(accO[v / 4][v % 4], rec[v]);
+                    if (g == 0 && P::ad(v) == NG - 1) add_w(sum[v / 4], wN[v % 4], softplus_lds_eval(accN[v / 4][v % 4], pend[ip++]));
+                    if (g > 0 && P::ad(v) == g - 1) add_w(sum[v / 4], wO[v % 4], softplus_lds_eval(accO[v / 4][v % 4], rec[v]));
                 }
 #pragma unroll
                 for (int v = 0; v < NV; v++)
@@ -259,18 +321,20 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
                 constexpr int NGc = NG;
                 const int gl = (g + LEAD) % NGc;
                 refill(g + LEAD < NGc ? cx : nx, gl * GK, (gl + 1) * GK < KS ? (gl + 1) * GK : KS);
+                if constexpr (W)
+                    if (g == 0) load_w(wx, wN);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     // after the last tile (accumulators accL; accP still holds the tile before it with its pending values)
-    auto drain = [&](const double4_t *accL, const double4_t *accP) {
+    auto drain = [&](const double4_t *accL, const double4_t *accP, const double *wL, const double *wP) {
         int ip = 0;
 #pragma unroll
         for (int v = 0; v < NV; v++)
-            if (P::ad(v) == NG - 1) sum[v / 4] += softplus_lds_eval(accP[v / 4][v % 4], pend[ip++]);
+            if (P::ad(v) == NG - 1) add_w(sum[v / 4], wP[v % 4], softplus_lds_eval(accP[v / 4][v % 4], pend[ip++]));
 #pragma unroll
-        for (int v = 0; v < NV; v++) sum[v / 4] += softplus_half_abs_lds(accL[v / 4][v % 4], sp_shift);
+        for (int v = 0; v < NV; v++) add_w(sum[v / 4], wL[v % 4], softplus_half_abs_lds(accL[v / 4][v % 4], sp_shift));
     };
     const std::true_type with_old;
     const std::false_type first_tile;
@@ -296,18 +360,21 @@ __global__ __launch_bounds__(NW * 64) void logdens_mfma_kernel(const double *__r
         // memory), so only the first unit waits for its first fragments
         const int lim = u + 1 < u_end ? nt : nt - 1;
         auto col = [&](int i) { return x0 + (size_t)(i < lim ? i : lim) * (KS * 64); };
+        auto wcol = [&](int i) { return W ? wt + (size_t)(t0 + (i < lim ? i : lim)) * 16 : wt; };
+#pragma unroll
+        for (int r = 0; r < 4; r++) w2[0][r] = w2[1][r] = 0.0;      // the zero pending records of a fresh unit meet finite weights
         if (u == u_begin) refill(col(0), 0, AR);
-        tile_block(col(0), col(1), acc2[0], acc2[1], first_tile);
+        tile_block(col(0), col(1), acc2[0], acc2[1], first_tile, wcol(0), w2[0], w2[1]);
         int i = 1;
         for (; i + 1 < nt; i += 2) {
-            tile_block(col(i), col(i + 1), acc2[1], acc2[0], with_old);
-            tile_block(col(i + 1), col(i + 2), acc2[0], acc2[1], with_old);
+            tile_block(col(i), col(i + 1), acc2[1], acc2[0], with_old, wcol(i), w2[1], w2[0]);
+            tile_block(col(i + 1), col(i + 2), acc2[0], acc2[1], with_old, wcol(i + 1), w2[0], w2[1]);
         }
         if (i < nt) {
-            tile_block(col(i), col(i + 1), acc2[1], acc2[0], with_old);
-            drain(acc2[1], acc2[0]);
+            tile_block(col(i), col(i + 1), acc2[1], acc2[0], with_old, wcol(i), w2[1], w2[0]);
+            drain(acc2[1], acc2[0], w2[1], w2[0]);
         } else {
-            drain(acc2[0], acc2[1]);
+            drain(acc2[0], acc2[1], w2[0], w2[1]);
         }
         // rows of the accumulator live on lane>>4 (4 groups) x 4 registers: fold the 4 groups
 #pragma unroll
@@ -341,6 +408,9 @@ struct UpdParams {
     double *cur, *acc, *acc_b, *buf;  // [ldc], [ldc], [ldc], [nout][ldc]
     double *batch, *accept_batch, *accept, *final_;  // chain-major outputs
     double *logdens_out;    // when non-null: just emit the log density (mcmchip_logdens)
+    // MCMCHIP_T_LOGISTIC_MODELS (log density only): the states as the caller gave them, (i, beta[d]) per chain, and the
+    // descriptor's parameter block (k, k x d masks, k log pseudo-priors, constant); prop holds beta * mask_i
+    const double *models_states, *models_par;
     int *flag;
 };
 
@@ -396,6 +466,16 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
         lin = fma(v, q.colsum[j], lin);
     }
     double ly = (0.5 * lin - part) + q.pad_term;
+    if (q.models_par) {         // tests/temp-par.R:39-56: the prior is over all of beta, masked or not
+        const double *st = q.models_states + (size_t)c * (d + 1);
+        const int k = (int)q.models_par[0];
+        const double *lpp = q.models_par + 1 + (size_t)k * d;
+        ss = 0.0;
+        for (int j = 0; j < d; j++) ss += st[1 + j] * st[1 + j];
+        ly = (ly - ss * q.prior_c) + lpp[k] + lpp[(int)st[0] - 1];
+        q.logdens_out[c] = ly;
+        return;
+    }
     ly -= ss * q.prior_c;
     if (q.logdens_out) { q.logdens_out[c] = ly; return; }
     if (ly == INFINITY) atomicOr(q.flag, FLAG_POSINF);
@@ -470,6 +550,23 @@ __global__ void soa_init_kernel(const double *__restrict__ init, long nchain, in
     prop[idx] = v;
 }
 
+// MCMCHIP_T_LOGISTIC_MODELS: states (i, beta[d]) chain-major -> beta * mask_i dimension-major (eta = X (beta * mask_i))
+__global__ void soa_init_models_kernel(const double *__restrict__ states, long nchain, int d, int dpad, long ldc,
+                                       const double *__restrict__ par, double *__restrict__ prop)
+{
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)dpad * ldc) return;
+    long c = idx % ldc;
+    int j = (int)(idx / ldc);
+    double v = 0.0;
+    if (c < nchain && j < d) {
+        const double *st = states + (size_t)c * (d + 1);
+        const int i = (int)st[0];
+        if (par[1 + (size_t)(i - 1) * d + j] != 0.0) v = st[1 + j];
+    }
+    prop[idx] = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 struct MfmaPlan {
     int ks, nc;
@@ -518,8 +615,13 @@ static void launch_ld(const MfmaPlan &pl, const mcmchip_target *t, const double 
 {
     constexpr int NC = KS > 32 ? 1 : MFMA_NC;
     dim3 grid((unsigned)pl.chain_blocks, (unsigned)pl.nsplit), block(MFMA_NW * 64);
-    hipLaunchKernelGGL((logdens_mfma_kernel<KS, NC, MFMA_NW, TC>), grid, block, 0, dc->stream, t->xt, prop,
-                       pl.ldc, partial, pl.tiles_per_unit, pl.units_per_split, pl.nunits, t->ntiles, dc->d_tables);
+    if (t->wt)
+        hipLaunchKernelGGL((logdens_mfma_kernel<KS, NC, MFMA_NW, TC, true>), grid, block, 0, dc->stream, t->xt, prop, pl.ldc,
+                           partial, pl.tiles_per_unit, pl.units_per_split, pl.nunits, t->ntiles, dc->d_tables, t->wt);
+    else
+        hipLaunchKernelGGL((logdens_mfma_kernel<KS, NC, MFMA_NW, TC, false>), grid, block, 0, dc->stream, t->xt, prop, pl.ldc,
+                           partial, pl.tiles_per_unit, pl.units_per_split, pl.nunits, t->ntiles, dc->d_tables,
+                           (const double *)nullptr);
 }
 
 static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const double *prop, double *partial,
@@ -604,7 +706,7 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     memset(&q, 0, sizeof q);
     q.nchain = p.nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nunits = pl.nunits;
     q.pad_term = (double)t->npad_rows * 0.6931471805599453;
-    q.prior_c = t->prior_c;
+    q.prior_c = t->kind == MCMCHIP_T_BINOMIAL_LOGIT ? 0.0 : t->prior_c;       // morph.Rnw:361-365 has no separate prior term
     q.nbatch = p.nbatch; q.blen = p.blen; q.nspac = p.nspac;
     q.scale_kind = p.scale_kind; q.scale = p.scale;
     q.nout = p.nout; q.sq_from = p.sq_from; q.out_map = p.out_map;
@@ -658,8 +760,13 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
     HIP_TRY(prop.alloc((size_t)t->dpad * ldc * 8));
     HIP_TRY(partial.alloc((size_t)pl.nunits * ldc * 8));
     long total = (long)t->dpad * ldc;
-    hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, states,
-                       nchain, t->d, t->dpad, ldc, state.as<double>(), prop.as<double>());
+    const bool models = t->kind == MCMCHIP_T_LOGISTIC_MODELS;
+    if (models)
+        hipLaunchKernelGGL(soa_init_models_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, states, nchain, t->d,
+                           t->dpad, ldc, t->par, prop.as<double>());
+    else
+        hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, states,
+                           nchain, t->d, t->dpad, ldc, state.as<double>(), prop.as<double>());
     HIP_TRY(hipGetLastError());
     timing_reset("logdens_mfma_kernel");
     timing_begin(s);
@@ -670,12 +777,13 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
     memset(&q, 0, sizeof q);
     q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nunits = pl.nunits;
     q.pad_term = (double)t->npad_rows * 0.6931471805599453;
-    q.prior_c = t->prior_c;
+    q.prior_c = t->kind == MCMCHIP_T_BINOMIAL_LOGIT ? 0.0 : t->prior_c;       // morph.Rnw:361-365 has no separate prior term
     q.nbatch = q.blen = q.nspac = 1;
     q.partial = partial.as<double>();
     q.colsum = t->colsum;
     q.state = state.as<double>(); q.prop = prop.as<double>();
     q.logdens_out = out;
+    if (models) { q.models_states = states; q.models_par = t->par; }
     hipLaunchKernelGGL(metrop_update_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q, -1L);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -723,7 +831,7 @@ int launch_logdens_mfma_noalloc(const mcmchip_target *t, const double *states, l
     memset(&q, 0, sizeof q);
     q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nunits = pl.nunits;
     q.pad_term = (double)t->npad_rows * 0.6931471805599453;
-    q.prior_c = t->prior_c;
+    q.prior_c = t->kind == MCMCHIP_T_BINOMIAL_LOGIT ? 0.0 : t->prior_c;       // morph.Rnw:361-365 has no separate prior term
     q.nbatch = q.blen = q.nspac = 1;
     q.partial = partial;
     q.colsum = t->colsum;

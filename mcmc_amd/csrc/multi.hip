@@ -65,6 +65,7 @@ int target_on_device(const mcmchip_target *t, int device, const mcmchip_target *
     if (!rc) rc = peer_copy((void **)&r->par, device, t->par, t->device, t->host_par.size() * 8);
     if (!rc) rc = peer_copy((void **)&r->xt, device, t->xt, t->device, (size_t)t->ntiles * t->ksteps * 64 * 8);
     if (!rc) rc = peer_copy((void **)&r->colsum, device, t->colsum, t->device, (size_t)t->dpad * 8);
+    if (!rc) rc = peer_copy((void **)&r->wt, device, t->wt, t->device, (size_t)t->ntiles * 16 * 8);
     if (!rc) rc = peer_copy((void **)&r->morph_center, device, t->morph_center, t->device, (size_t)t->d * 8);
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = set_error(MCMCHIP_EHIP, "replicating the descriptor onto device %d failed", device);
     if (rc) { mcmchip_target_destroy(r); return rc; }

@@ -248,6 +248,65 @@ def test_logdens_mfma_vs_oracle(api, oracle_mod, n, d, C):
     assert rel(got_m, ref) < RTOL and rel(got_s, ref) < RTOL
 
 
+@pytest.mark.parametrize("n,d,C", [(100_000, 5, 300), (120_001, 64, 130), (5003, 20, 64), (40_000, 128, 70), (30_000, 200, 40)])
+def test_logdens_mfma_binomial_and_models_vs_oracle(api, oracle_mod, n, d, C):
+    """The two other kinds with a design matrix on the matrix cores (same contraction, another epilogue): the binomial
+    regression of vignettes/morph.Rnw:361-365, whose totals weight the softplus terms (one more operand of the running
+    sum's fma; the linear part goes through the column sums), and the model-selection posterior of tests/temp-par.R:39-56,
+    whose masks are folded into the states.  MFMA and stream kernels against the oracle, 1e-12."""
+    rng = np.random.default_rng(n + d)
+    X, y, beta = _synthetic(n, d, seed=n)
+    # binomial regression: posterior totals w_l > 0 (not integers: the conjugate prior adds to them), successes in (0, w_l)
+    tot = rng.integers(1, 30, n) + 0.5 + rng.random(n)
+    succ = tot * (0.05 + 0.9 * rng.random(n))
+    states = beta + 0.3 * rng.standard_normal((C, d))
+    states[0] *= 25.0
+    kw = dict(x=X, y=succ, par=tot)
+    ref = oracle_mod.logdens(oracle_mod.Target(abi.T_BINOMIAL_LOGIT, d, **kw), states)
+    tg = api.Target(abi.T_BINOMIAL_LOGIT, d, **kw)
+    got_m = api.logdens(tg, states, path=abi.PATH_MFMA)
+    got_s = api.logdens(tg, states, path=abi.PATH_STREAM)
+    assert rel(got_m, ref) < RTOL and rel(got_s, ref) < RTOL
+    # model selection: k random masks (intercept always in), log pseudo-priors, a constant
+    k = 6
+    masks = (rng.random((k, d)) < 0.6).astype(float)
+    masks[:, 0] = 1.0
+    masks[0] = 1.0
+    par = abi.logistic_models_par(masks, log_pseudo_prior=rng.standard_normal(k), constant=-1.25)
+    kw = dict(x=X, y=y, prior_c=0.125, par=par)
+    st = np.empty((C, d + 1))
+    st[:, 0] = rng.integers(1, k + 1, C)
+    st[:, 1:] = states
+    ref = oracle_mod.logdens(oracle_mod.Target(abi.T_LOGISTIC_MODELS, d, **kw), st)
+    tg = api.Target(abi.T_LOGISTIC_MODELS, d, **kw)
+    got_m = api.logdens(tg, st, path=abi.PATH_MFMA)
+    got_s = api.logdens(tg, st, path=abi.PATH_STREAM)
+    assert rel(got_m, ref) < RTOL and rel(got_s, ref) < RTOL
+
+
+def test_metrop_mfma_binomial_injected_vs_oracle(api, oracle_mod):
+    """metrop on the binomial regression through the MFMA path with injected draws: the oracle's decisions and finals."""
+    n, d, C, nbatch, blen, nspac = 20_000, 12, 128, 5, 3, 2
+    niter = nbatch * blen * nspac
+    rng = np.random.default_rng(5)
+    X, y, beta = _synthetic(n, d, seed=3)
+    tot = rng.integers(1, 30, n) + 0.5
+    succ = tot / (1 + np.exp(-X @ beta))
+    kw = dict(x=X, y=succ, par=tot)
+    init = beta + 0.003 * rng.standard_normal((C, d))
+    z, u = rng.standard_normal((C, niter, d)), rng.random((C, niter))
+    ref = oracle_mod.metrop(oracle_mod.Target(abi.T_BINOMIAL_LOGIT, d, **kw), init, nbatch, blen, nspac, scale=0.004, z=z, u=u,
+                            nthreads=16)
+    o = api.metrop(api.Target(abi.T_BINOMIAL_LOGIT, d, **kw), init, nbatch, blen, nspac, scale=0.004, z=z, u=u, path=abi.PATH_MFMA)
+    assert o["path"] == "mfma"
+    assert np.array_equal(o["accept.batch"], ref["accept_batch"])
+    assert np.array_equal(o["final"], ref["final"])
+    assert rel(o["batch"], ref["batch"]) < RTOL
+    assert 0.05 < o["accept"].mean() < 0.95
+    auto = api.metrop(api.Target(abi.T_BINOMIAL_LOGIT, d, **kw), init, nbatch, blen, nspac, scale=0.004, z=z, u=u)
+    assert auto["path"] == "mfma" and np.array_equal(auto["final"], o["final"])      # n d large: AUTO takes the matrix cores
+
+
 @pytest.mark.parametrize("scale_kind", ["scalar", "matrix"])
 @pytest.mark.parametrize("d", [16, 80, 200])
 def test_metrop_mfma_injected_vs_oracle(api, oracle_mod, scale_kind, d):
