@@ -140,6 +140,12 @@ enum {
     MCMCHIP_RNG_PHILOX = 2
 };
 
+/* which kernels evaluate the log density.  STREAM: the persistent per-chain kernel (every descriptor, debug trace).
+ * MFMA: the contraction X . Theta on the fp64 matrix cores, for the descriptors that carry a design matrix of d <= 256
+ * columns -- MCMCHIP_T_LOGISTIC and MCMCHIP_T_BINOMIAL_LOGIT (metrop and logdens, morphed or not; no debug trace) and
+ * MCMCHIP_T_LOGISTIC_MODELS (logdens only).  AUTO takes MFMA when n * d >= 65 536, or n >= 4096 with >= 4096 chains (at
+ * least 64 chains and n >= 1024 in any case).  The two sum the observations in different orders: a sharded run that
+ * must reproduce an unsharded one bit for bit pins the path. */
 enum { MCMCHIP_PATH_AUTO = 0, MCMCHIP_PATH_STREAM = 1, MCMCHIP_PATH_MFMA = 2 };
 
 /* ------------------------------------------------------------------ */

@@ -353,7 +353,7 @@ int mcmchip_target_create(const mcmchip_target_desc *desc, int desc_device_ptrs,
             if (k < 2 || desc->npar != 1 + k * desc->d + k + 1) { rc = set_error(MCMCHIP_EINVAL, "logistic-models descriptor: par must be k, k x d masks, k log pseudo-priors, constant"); break; }
         }
         if (desc->kind == MCMCHIP_T_BINOMIAL_LOGIT && desc->npar != desc->n) { rc = set_error(MCMCHIP_EINVAL, "binomial descriptor needs one total per row of x"); break; }
-        if (desc->kind == MCMCHIP_T_BINOMIAL_LOGIT && desc->d <= MCMCHIP_MFMA_MAXD && !desc->morph_flags) {
+        if (desc->kind == MCMCHIP_T_BINOMIAL_LOGIT && desc->d <= MCMCHIP_MFMA_MAXD) {
             rc = build_mfma_tiles(t, dc->stream);      // row weights = the totals (par, in HBM by now)
             if (rc) break;
         }
@@ -437,8 +437,7 @@ int mcmchip_logdens(const mcmchip_target *t, const double *states, int64_t nchai
     OutBuf ob;
     HIP_TRY(in.set(states, (size_t)nchain * w * 8, device_ptrs, dc->stream));
     HIP_TRY(ob.set(out, (size_t)nchain * 8, device_ptrs));
-    if (path == MCMCHIP_PATH_MFMA && t->morph_flags) return set_error(MCMCHIP_EINVAL, "the MFMA path does not take a morphed descriptor");
-    bool mfma = (path == MCMCHIP_PATH_MFMA) || (path == MCMCHIP_PATH_AUTO && t->xt && !t->morph_flags && mfma_pays(t, nchain));
+    bool mfma = (path == MCMCHIP_PATH_MFMA) || (path == MCMCHIP_PATH_AUTO && t->xt && mfma_pays(t, nchain));
     int rc;
     if (mfma) rc = launch_logdens_mfma(t, in.as<double>(), nchain, ob.as<double>(), dc);
     else rc = launch_logdens_stream(t, in.as<double>(), nchain, ob.as<double>(), dc->stream);
@@ -457,7 +456,7 @@ int mcmchip_logdens_noalloc(const mcmchip_target *t, const double *states, int64
     if (!dc) return MCMCHIP_EHIP;
     if (!t || !states || !out || nchain <= 0) return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_logdens_noalloc");
     if (int rc = check_target_device(t)) return rc;
-    if (t->morph_flags) return set_error(MCMCHIP_EINVAL, "the MFMA path does not take a morphed descriptor");
+    if (t->morph_flags) return set_error(MCMCHIP_EINVAL, "mcmchip_logdens_noalloc does not take a morphed descriptor (use mcmchip_logdens)");
     if (is_temper_kind(t->kind)) return set_error(MCMCHIP_EINVAL, "mcmchip_logdens_noalloc takes metrop descriptors (use mcmchip_logdens)");
     return launch_logdens_mfma_noalloc(t, states, nchain, out, dc);
 }
@@ -523,9 +522,9 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
         return set_error(MCMCHIP_EINVAL, "debug requested but trace outputs are NULL");
     if (!o->accept || (!o->batch && nout > 0) || !o->final || !o->accept_batch) return set_error(MCMCHIP_EINVAL, "null output");
 
-    bool mfma_ok = t->xt && !a->debug && !t->morph_flags;
+    bool mfma_ok = t->xt && !a->debug;
     bool mfma = (a->path == MCMCHIP_PATH_MFMA) || (a->path == MCMCHIP_PATH_AUTO && mfma_ok && mfma_pays(t, nchain));
-    if (mfma && !mfma_ok) return set_error(MCMCHIP_EINVAL, "MFMA path needs a logistic or binomial-regression descriptor with d <= %d, no morph and debug = FALSE", MCMCHIP_MFMA_MAXD);
+    if (mfma && !mfma_ok) return set_error(MCMCHIP_EINVAL, "MFMA path needs a logistic or binomial-regression descriptor with d <= %d and debug = FALSE", MCMCHIP_MFMA_MAXD);
 
     hipStream_t s = dc->stream;
     const int dp = a->device_ptrs;

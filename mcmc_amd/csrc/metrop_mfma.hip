@@ -38,6 +38,7 @@
 // Roofline: fp64 MFMA.  Algorithmic flops per launch = 2 * n * d * C.
 #include "kernels.h"
 #include "philox.h"
+#include "targets.h"
 #include <type_traits>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -411,8 +412,54 @@ struct UpdParams {
     // MCMCHIP_T_LOGISTIC_MODELS (log density only): the states as the caller gave them, (i, beta[d]) per chain, and the
     // descriptor's parameter block (k, k x d masks, k log pseudo-priors, constant); prop holds beta * mask_i
     const double *models_states, *models_par;
+    // morph.metrop (R/morph.R:121-181): state / prop hold the morphed chain; theta = inverse(prop) is what the density
+    // kernel contracts with X, theta_state = inverse(state) is what the output functional sees (morph.R:95-106), lj the
+    // proposal's log.jacobian (morph.R:16-28).  No morph: theta == prop, theta_state == state, lj == nullptr.
+    int morph_flags;
+    double morph_b, morph_r, morph_p;
+    const double *morph_center;
+    double *theta, *theta_state, *lj;
     int *flag;
 };
+
+// theta[:, c] = inverse(prop[:, c]) and lj[c] = log.jacobian(prop[:, c]); one lane per chain, the sum of squares in the
+// reference's order (morph.R:8-13)
+__device__ __forceinline__ void morph_proposal(const UpdParams &q, long c)
+{
+    TargetView t;
+    t.morph_flags = q.morph_flags; t.morph_b = q.morph_b; t.morph_r = q.morph_r; t.morph_p = q.morph_p;
+    const int d = q.d;
+    const long ldc = q.ldc;
+    const bool shaped = q.morph_flags & (MCMCHIP_MORPH_EXPO | MCMCHIP_MORPH_SUBEXPO);
+    double nrm = 0.0;
+    if (shaped) {
+        double ss = 0.0;
+        for (int j = 0; j < d; j++) ss += q.prop[(size_t)j * ldc + c] * q.prop[(size_t)j * ldc + c];
+        nrm = sqrt(ss);
+    }
+    const double fi = (shaped && nrm != 0) ? morph_finv(t, nrm) : 0.0;
+    for (int j = 0; j < d; j++) {
+        double v = q.prop[(size_t)j * ldc + c];
+        if (shaped) v = (nrm == 0) ? 0.0 : fi * v / nrm;
+        if (q.morph_flags & MCMCHIP_MORPH_CENTER) v += q.morph_center[j];
+        q.theta[(size_t)j * ldc + c] = v;
+    }
+    double lj = 0.0;
+    if (shaped) {
+        if (nrm == 0) lj = d * log(morph_dfinv(t, nrm));                                       // morph.R:22-23
+        else lj = log(morph_dfinv(t, nrm)) + (d - 1) * (log(morph_finv(t, nrm)) - log(nrm));   // morph.R:25
+    }
+    q.lj[c] = lj;
+}
+
+__global__ __launch_bounds__(256) void morph_init_kernel(UpdParams q)      // the initial state: theta, theta_state, lj
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= q.nchain) return;
+    morph_proposal(q, c);
+    if (q.theta_state != q.theta)
+        for (int j = 0; j < q.d; j++) q.theta_state[(size_t)j * q.ldc + c] = q.theta[(size_t)j * q.ldc + c];
+}
 
 __device__ __forceinline__ void make_proposal(const UpdParams &q, long c, long l_next)
 {
@@ -446,6 +493,7 @@ __device__ __forceinline__ void make_proposal(const UpdParams &q, long c, long l
             q.prop[(size_t)j * ldc + c] = a;
         }
     }
+    if (q.morph_flags) morph_proposal(q, c);
 }
 
 // l == -1: initial state (prop holds a copy of the state): record cur, draw the first proposal
@@ -461,7 +509,7 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     for (int s = 0; s < q.nunits; s++) part += q.partial[(size_t)s * ldc + c];
     double ss = 0.0, lin = 0.0;
     for (int j = 0; j < d; j++) {
-        const double v = q.prop[(size_t)j * ldc + c];
+        const double v = q.theta[(size_t)j * ldc + c];
         ss += v * v;
         lin = fma(v, q.colsum[j], lin);
     }
@@ -477,6 +525,8 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
         return;
     }
     ly -= ss * q.prior_c;
+    // morph.R:166-179: lud(inverse(y)) + log.jacobian(y); -Inf, NaN and +Inf of the density pass through
+    if (q.lj && !(ly == -INFINITY || isnan(ly) || ly == INFINITY)) ly += q.lj[c];
     if (q.logdens_out) { q.logdens_out[c] = ly; return; }
     if (ly == INFINITY) atomicOr(q.flag, FLAG_POSINF);
     else if (isnan(ly)) atomicOr(q.flag, FLAG_NAN);
@@ -506,6 +556,8 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     }
     if (accept) {
         for (int j = 0; j < d; j++) q.state[(size_t)j * ldc + c] = q.prop[(size_t)j * ldc + c];
+        if (q.theta_state != q.state)
+            for (int j = 0; j < d; j++) q.theta_state[(size_t)j * ldc + c] = q.theta[(size_t)j * ldc + c];
         q.cur[c] = ly;
         q.acc[c] += 1.0;
         q.acc_b[c] += 1.0;
@@ -516,7 +568,7 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     const long ib = lb / q.blen;
     if (is == q.nspac - 1) {                   // metrop.c:273-275
         for (int k = 0; k < q.nout; k++) {
-            double v = q.state[(size_t)q.out_map[k] * ldc + c];
+            double v = q.theta_state[(size_t)q.out_map[k] * ldc + c];
             if (k >= q.sq_from) v = mul_nofma(v, v);
             q.buf[(size_t)k * ldc + c] = add_nofma(q.buf[(size_t)k * ldc + c], v);
         }
@@ -693,9 +745,16 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     ws.want((size_t)ldc * 8);
     ws.want((size_t)ldc * 8);
     ws.want((size_t)(p.nout > 0 ? p.nout : 1) * ldc * 8);
+    if (t->morph_flags) {
+        ws.want((size_t)t->dpad * ldc * 8);
+        ws.want((size_t)t->dpad * ldc * 8);
+        ws.want((size_t)ldc * 8);
+    }
     if (int rc = ws.reserve()) return rc;
     double *state = ws.take(), *prop = ws.take(), *partial = ws.take(), *cur = ws.take(), *acc = ws.take(),
            *acc_b = ws.take(), *buf = ws.take();
+    double *theta = prop, *theta_state = state, *lj = nullptr;
+    if (t->morph_flags) { theta = ws.take(); theta_state = ws.take(); lj = ws.take(); }
 
     long total = (long)t->dpad * ldc;
     hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.initial,
@@ -719,6 +778,14 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     q.batch = p.batch; q.accept_batch = p.accept_batch; q.accept = p.accept; q.final_ = p.final_;
     q.logdens_out = nullptr;
     q.flag = p.flag;
+    q.morph_flags = t->morph_flags; q.morph_b = t->morph_b; q.morph_r = t->morph_r; q.morph_p = t->morph_p;
+    q.morph_center = t->morph_center;
+    q.theta = theta; q.theta_state = theta_state; q.lj = lj;
+    if (t->morph_flags) {
+        HIP_TRY(hipMemsetAsync(theta, 0, (size_t)t->dpad * ldc * 8, s));       // padded rows and chains: zeros
+        hipLaunchKernelGGL(morph_init_kernel, dim3((unsigned)((p.nchain + 255) / 256)), dim3(256), 0, s, q);
+        HIP_TRY(hipGetLastError());
+    }
 
     const long niter = (long)p.nbatch * p.blen * p.nspac;
     dim3 ugrid((unsigned)((p.nchain + 255) / 256)), ublock(256);
@@ -729,7 +796,7 @@ int run_metrop_mfma(const mcmchip_target *t, const MetropDev &p, DeviceCtx *dc)
     long group = 1, in_group = 0;
     for (long l = -1; l < niter; l++) {
         timing_begin(s);
-        int rc = launch_logdens(pl, t, prop, partial, dc);
+        int rc = launch_logdens(pl, t, theta, partial, dc);
         timing_end(s);
         if (rc) return rc;
         hipLaunchKernelGGL(metrop_update_kernel, ugrid, ublock, 0, s, q, l);
@@ -755,10 +822,11 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
     hipStream_t s = dc->stream;
     MfmaPlan pl = make_plan(t, nchain, dc->num_cu);
     const long ldc = pl.ldc;
-    DevBuf state, prop, partial;
+    DevBuf state, prop, partial, ljbuf;
     HIP_TRY(state.alloc((size_t)t->dpad * ldc * 8));
     HIP_TRY(prop.alloc((size_t)t->dpad * ldc * 8));
     HIP_TRY(partial.alloc((size_t)pl.nunits * ldc * 8));
+    if (t->morph_flags) HIP_TRY(ljbuf.alloc((size_t)ldc * 8));
     long total = (long)t->dpad * ldc;
     const bool models = t->kind == MCMCHIP_T_LOGISTIC_MODELS;
     if (models)
@@ -768,20 +836,32 @@ int launch_logdens_mfma(const mcmchip_target *t, const double *states, long ncha
         hipLaunchKernelGGL(soa_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, states,
                            nchain, t->d, t->dpad, ldc, state.as<double>(), prop.as<double>());
     HIP_TRY(hipGetLastError());
-    timing_reset("logdens_mfma_kernel");
-    timing_begin(s);
-    int rc = launch_logdens(pl, t, prop.as<double>(), partial.as<double>(), dc);
-    timing_end(s);
-    if (rc) return rc;
     UpdParams q;
     memset(&q, 0, sizeof q);
     q.nchain = nchain; q.ldc = ldc; q.d = t->d; q.dpad = t->dpad; q.nunits = pl.nunits;
+    // morphed descriptor: prop holds the morphed states, the contraction runs on state = inverse(prop) (its padding is
+    // zero from soa_init_kernel, the rest is overwritten)
+    q.prop = prop.as<double>();
+    q.theta = t->morph_flags ? state.as<double>() : prop.as<double>();
+    q.theta_state = q.theta;
+    q.morph_flags = t->morph_flags; q.morph_b = t->morph_b; q.morph_r = t->morph_r; q.morph_p = t->morph_p;
+    q.morph_center = t->morph_center;
+    q.lj = t->morph_flags ? ljbuf.as<double>() : nullptr;
+    if (t->morph_flags) {
+        hipLaunchKernelGGL(morph_init_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q);
+        HIP_TRY(hipGetLastError());
+    }
+    timing_reset("logdens_mfma_kernel");
+    timing_begin(s);
+    int rc = launch_logdens(pl, t, q.theta, partial.as<double>(), dc);
+    timing_end(s);
+    if (rc) return rc;
     q.pad_term = (double)t->npad_rows * 0.6931471805599453;
     q.prior_c = t->kind == MCMCHIP_T_BINOMIAL_LOGIT ? 0.0 : t->prior_c;       // morph.Rnw:361-365 has no separate prior term
     q.nbatch = q.blen = q.nspac = 1;
     q.partial = partial.as<double>();
     q.colsum = t->colsum;
-    q.state = state.as<double>(); q.prop = prop.as<double>();
+    q.state = state.as<double>();
     q.logdens_out = out;
     if (models) { q.models_states = states; q.models_par = t->par; }
     hipLaunchKernelGGL(metrop_update_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q, -1L);
@@ -835,7 +915,7 @@ int launch_logdens_mfma_noalloc(const mcmchip_target *t, const double *states, l
     q.nbatch = q.blen = q.nspac = 1;
     q.partial = partial;
     q.colsum = t->colsum;
-    q.state = prop; q.prop = prop;
+    q.state = prop; q.prop = prop; q.theta = prop; q.theta_state = prop;
     q.logdens_out = out;
     hipLaunchKernelGGL(metrop_update_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, q, -1L);
     HIP_TRY(hipGetLastError());

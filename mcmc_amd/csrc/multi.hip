@@ -172,7 +172,7 @@ int mcmchip_metrop_multi(const mcmchip_target *t, const mcmchip_metrop_args *a, 
     // AUTO looks at the chain count: decide on the whole call, so that a split run takes the kernel the unsplit one takes
     int path = a->path;
     if (path == MCMCHIP_PATH_AUTO) {
-        const bool mfma_ok = t->xt && !a->debug && !t->morph_flags;
+        const bool mfma_ok = t->xt && !a->debug;
         const bool pays = a->nchain >= 64 && t->n >= 1024 && ((long)t->n * t->d >= 65536 || (t->n >= 4096 && a->nchain >= 4096));
         path = mfma_ok && pays ? MCMCHIP_PATH_MFMA : MCMCHIP_PATH_STREAM;
     }

@@ -758,6 +758,46 @@ def test_morphed_metrop_trajectory_vs_oracle(api, oracle_mod, kw, outfun):
     assert 0.05 < o["accept"].mean() < 0.95
 
 
+@pytest.mark.parametrize("kw", [dict(b=0.4), dict(r=0.5, p=3), dict(b=0.3, r=1.0, p=3, center=True), dict(center=True)])
+@pytest.mark.parametrize("kind", ["logistic", "binomial"])
+def test_morphed_mfma_path_vs_oracle(api, oracle_mod, kw, kind):
+    """morph.metrop on the matrix cores: the chain runs on the morphed state, the contraction on inverse(state), the
+    log.jacobian is added by the update kernel (morph.R:166-179).  The worked example of vignettes/morph.Rnw:361-365 is the
+    binomial regression; log densities at 1e-12, and an injected-draw run with the oracle's decisions and finals."""
+    from mcmc_amd import morph
+    rng = np.random.default_rng(21)
+    n, d, C, nbatch, blen, nspac = 6000, 7, 96, 6, 3, 2
+    niter = nbatch * blen * nspac
+    X, y, beta = _synthetic(n, d, seed=4)
+    kw = dict(kw)
+    if kw.pop("center", False):
+        kw["center"] = list(np.round(beta, 2))
+    m = morph(**kw)
+    if kind == "logistic":
+        K, tkw = abi.T_LOGISTIC, dict(x=X, y=y, prior_c=0.125)
+    else:
+        tot = rng.integers(1, 30, n) + 0.5
+        K, tkw = abi.T_BINOMIAL_LOGIT, dict(x=X, y=tot / (1 + np.exp(-X @ beta)), par=tot)
+    states = np.concatenate([0.8 * rng.standard_normal((C - 1, d)), np.zeros((1, d))])      # morphed states, the origin among them
+    want = oracle_mod.logdens(oracle_mod.Target(K, d, morph=m, **tkw), states)
+    tg = api.Target(K, d, morph=m, **tkw)
+    got_m = api.logdens(tg, states, path=abi.PATH_MFMA)
+    got_s = api.logdens(tg, states, path=abi.PATH_STREAM)
+    assert np.all(np.isfinite(want))
+    assert rel(got_m, want) < RTOL and rel(got_s, want) < RTOL
+    init = m.transform(beta + 0.02 * rng.standard_normal((C, d))) if hasattr(m, "transform") else states
+    z, u = rng.standard_normal((C, niter, d)), rng.random((C, niter))
+    sc = 0.02
+    ref = oracle_mod.metrop(oracle_mod.Target(K, d, morph=m, **tkw), init, nbatch, blen, nspac, scale=sc, outfun="moments2",
+                            z=z, u=u, nthreads=16)
+    o = api.metrop(tg, init, nbatch, blen, nspac, scale=sc, outfun="moments2", z=z, u=u, path=abi.PATH_MFMA)
+    assert o["path"] == "mfma"
+    assert np.array_equal(o["accept.batch"], ref["accept_batch"])
+    assert np.array_equal(o["final"], ref["final"])
+    assert np.max(np.abs(o["batch"] - ref["batch"]) / np.maximum(np.abs(ref["batch"]), 1.0)) < 1e-12
+    assert 0.02 < o["accept"].mean() < 0.98
+
+
 def test_morph_metrop_api_and_restart(api):
     # tests/morph.metrop.R:8-18 (runs; the transformation can be changed), tests/saveseedmorph.R (restart
     # determinism), R/morph.metrop.R:42-49 (nspac is not forwarded on the first call), 55-62 (.morph.unmorph)
@@ -808,8 +848,9 @@ def test_morph_descriptor_errors(api):
         api.Target(abi.T_WITCH, 2, par=[0.5, 0.25], morph=morph(b=1))
     X = np.ones((8, 2))
     y = np.zeros(8)
-    tg = api.Target(abi.T_LOGISTIC, 2, x=X, y=y, prior_c=0.125, morph=morph(b=1))
-    with pytest.raises(api.McmcHipError, match="MFMA path"):
+    # a morphed descriptor without a design matrix has no MFMA path (a morphed logistic one does since round 3)
+    tg = api.Target(abi.T_STUDENT_T, 2, par=[3.0], morph=morph(b=1))
+    with pytest.raises(api.McmcHipError, match="MFMA"):
         api.logdens(tg, np.zeros((4, 2)), path=abi.PATH_MFMA)
 
 
