@@ -212,7 +212,14 @@ enum {
 /* temper kernels (args.path; AUTO = 0 picks): LDS = one wavefront per ensemble with the state in LDS (any shape,
  * serial tempering, debug trace); RUN = lane-per-component registers, runs of iterations on disjoint components
  * executed together (parallel, k <= 64, p <= 4, closed-form descriptors, no trace).  Same results bit for bit. */
-enum { MCMCHIP_PATH_LDS = 1, MCMCHIP_PATH_RUN = 2 };
+enum { MCMCHIP_PATH_LDS = 1, MCMCHIP_PATH_RUN = 2, MCMCHIP_PATH_TMFMA = 3 };
+/* TMFMA (temper_mfma.hip): MCMCHIP_T_LOGISTIC_MODELS over a large data set.  The ensembles advance in lockstep and the
+ * one or two log densities an iteration needs per ensemble (temper.c:547-845) are one launch of the fp64 matrix-core
+ * density kernel over 2 nens states; same draws in the same order as the other two, log densities equal to rounding
+ * (another summation order over the observations).  Identity / INDEX / MOMENTS2 output, no trace.  AUTO takes it from
+ * MCMCHIP_TMFMA_MIN_N observations on (measured, 1024 ensembles of 8 sub-models: 106 against 134 us per iteration at
+ * n = 4096, 119 / 424 at 16 384, 0.69 / 10.1 ms at 262 144; tools/temper_paths.py). */
+#define MCMCHIP_TMFMA_MIN_N 8192
 
 typedef struct mcmchip_temper_args {
     int64_t nens;

@@ -19,7 +19,7 @@ SCALE_CONSTANT, SCALE_DIAGONAL, SCALE_FULL, SCALE_LIST = 1, 2, 3, 8
 OUT_IDENTITY, OUT_INDEX, OUT_MOMENTS2 = 0, 1, 2
 RNG_INJECTED, RNG_PHILOX = 1, 2
 PATH_AUTO, PATH_STREAM, PATH_MFMA = 0, 1, 2
-PATH_LDS, PATH_RUN = 1, 2      # temper kernels (mcmchip_temper_args.path)
+PATH_LDS, PATH_RUN, PATH_TMFMA = 1, 2, 3      # temper kernels (mcmchip_temper_args.path)
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

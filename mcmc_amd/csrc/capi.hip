@@ -693,7 +693,7 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     }
     if (a->out_kind == MCMCHIP_TOUT_WITCH_CORNER && t->kind != MCMCHIP_T_WITCH)
         return set_error(MCMCHIP_EINVAL, "the corner-indicator output functional belongs to the witch's hat descriptor");
-    if (a->path != MCMCHIP_PATH_AUTO && a->path != MCMCHIP_PATH_LDS && a->path != MCMCHIP_PATH_RUN)
+    if (a->path != MCMCHIP_PATH_AUTO && a->path != MCMCHIP_PATH_LDS && a->path != MCMCHIP_PATH_RUN && a->path != MCMCHIP_PATH_TMFMA)
         return set_error(MCMCHIP_EINVAL, "unknown temper path %d", a->path);
     const bool tmapped = a->out_kind == MCMCHIP_TOUT_INDEX || a->out_kind == MCMCHIP_TOUT_MOMENTS2;
     const int nout = tmapped ? (int)tmap.size()
@@ -750,7 +750,11 @@ int mcmchip_temper(const mcmchip_target *t, const mcmchip_temper_args *a, mcmchi
     q.dbg_coproposal = dcop.as<double>();
     q.flag = dc->d_flag;
     timing_reset("temper_kernel");
-    int rc = launch_temper(q, s);            // one or more timed launches
+    // model-selection posterior over a large data set: lockstep ensembles, densities on the matrix cores
+    // (temper_mfma.hip); one wavefront per ensemble otherwise
+    const bool tmfma = a->path == MCMCHIP_PATH_TMFMA ||
+                       (a->path == MCMCHIP_PATH_AUTO && temper_mfma_applies(t, q) && t->n >= MCMCHIP_TMFMA_MIN_N);
+    int rc = tmfma ? run_temper_mfma(t, q, dc) : launch_temper(q, s);            // one or more timed launches
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     rc = check_flag(dc, true);
     if (rc) return rc;

@@ -89,6 +89,12 @@ struct TemperDev {
     int *flag;
 };
 int launch_temper(const TemperDev &p, hipStream_t s);
+// temper_mfma.hip: the ensembles in lockstep, log densities of the model-selection posterior on the matrix cores
+bool temper_mfma_applies(const mcmchip_target *t, const TemperDev &q);
+int run_temper_mfma(const mcmchip_target *t, const TemperDev &q, DeviceCtx *dc);
+// metrop_mfma.hip, for that driver
+int mfma_density_plan(const mcmchip_target *t, long nchain, DeviceCtx *dc, long *ldc, int *nunits);
+int mfma_density_launch(const mcmchip_target *t, long nchain, const double *theta, double *partial, DeviceCtx *dc);
 
 // capi.hip: VAL_* bits of a device-resident input (non-finite values; serial-tempering component index)
 int device_validate(DeviceCtx *dc, const double *v, long n, long stride, int k, int *bits);

@@ -700,6 +700,22 @@ static int launch_logdens(const MfmaPlan &pl, const mcmchip_target *t, const dou
     return MCMCHIP_OK;
 }
 
+// the density launch for other drivers (temper_mfma.hip): the plan's chain stride and unit count, and one launch over
+// `nchain` columns of theta ([dpad][ldc], zero padded) into partial ([nunits][ldc])
+int mfma_density_plan(const mcmchip_target *t, long nchain, DeviceCtx *dc, long *ldc, int *nunits)
+{
+    if (!t->xt) return set_error(MCMCHIP_EINVAL, "target has no MFMA tiles");
+    const MfmaPlan pl = make_plan(t, nchain, dc->num_cu);
+    *ldc = pl.ldc;
+    *nunits = pl.nunits;
+    return MCMCHIP_OK;
+}
+int mfma_density_launch(const mcmchip_target *t, long nchain, const double *theta, double *partial, DeviceCtx *dc)
+{
+    const MfmaPlan pl = make_plan(t, nchain, dc->num_cu);
+    return launch_logdens(pl, t, theta, partial, dc);
+}
+
 // carve the MFMA path's scratch buffers out of the device's cached workspace (256-byte aligned pieces)
 struct Workspace {
     DeviceCtx *dc;

@@ -1281,3 +1281,59 @@ def test_posinf_and_nan_mid_run_are_the_references_errors(api):
     for path in (abi.PATH_RUN, abi.PATH_LDS):
         with pytest.raises(Exception, match="returned NA or NaN"):
             api.temper(tg, init, nbr, 20, 5, 1, 1e160, parallel=True, seed=4, _path=path)
+
+@pytest.mark.parametrize("parallel", [True, False])
+@pytest.mark.parametrize("outfun", [None, "moments2"])
+def test_temper_mfma_path_vs_oracle_and_lds_kernel(api, oracle_mod, parallel, outfun):
+    """temper_mfma.hip: tempering over the model-selection posterior with the ensembles in lockstep and the log densities
+    on the matrix cores (one launch of the density kernel over 2 nens states per iteration).  Injected draws: the
+    oracle's acceptance tables, batch means and final states; device Philox: the LDS kernel's.  A random neighbour graph,
+    a list of scales, n not a multiple of anything."""
+    rng = np.random.default_rng(31 + int(parallel))
+    n, p, k, E = 6007, 5, 6, 40
+    nbatch, blen, nspac = 6, 4, 3
+    niter = nbatch * blen * nspac
+    X = rng.standard_normal((n, p)) / np.sqrt(p)
+    X[:, 0] = 1.0
+    beta = 0.5 * rng.standard_normal(p)
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    masks = (rng.random((k, p)) < 0.6).astype(float)
+    masks[:, 0] = 1.0
+    masks[0] = 1.0
+    nb = np.zeros((k, k), dtype=bool)
+    for i in range(k - 1):
+        nb[i, i + 1] = nb[i + 1, i] = True
+    nb[0, 3] = nb[3, 0] = True
+    par = abi.logistic_models_par(masks, log_pseudo_prior=0.3 * rng.standard_normal(k), constant=-2.0)
+    kw = dict(x=X, y=y, prior_c=0.125, par=par)
+    scale = [0.02 * (1 + i) * np.ones(p) for i in range(k)]            # one diagonal scale per component (temper.c:998-999)
+    if parallel:
+        init = beta + 0.05 * rng.standard_normal((E, k, p))
+    else:
+        init = np.column_stack([rng.integers(1, k + 1, E).astype(float), beta + 0.05 * rng.standard_normal((E, p))])
+    unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
+    okind = oracle_mod.TOUT_MOMENTS2 if outfun == "moments2" else oracle_mod.TOUT_NONE
+    ref = oracle_mod.temper(oracle_mod.Target(abi.T_LOGISTIC_MODELS, p, **kw), init, nb, nbatch, blen, nspac, scale,
+                            parallel=parallel, unif=unif, norm=norm, out_kind=okind, nthreads=16)
+    tg = api.Target(abi.T_LOGISTIC_MODELS, p, **kw)
+    o = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=parallel, unif=unif, norm=norm, outfun=outfun,
+                   _path=abi.PATH_TMFMA)
+    assert api.last_kernel_time()[0] == "logdens_mfma_kernel"
+    assert np.array_equal(o["final"], ref["final"])
+    assert np.array_equal(np.isnan(o["accepti"]), np.isnan(ref["accepti"]))
+    assert np.array_equal(np.nan_to_num(o["accepti"]), np.nan_to_num(ref["accepti"]))
+    assert np.array_equal(np.nan_to_num(o["acceptx"]), np.nan_to_num(ref["acceptx"]))
+    assert np.max(np.abs(o["batch"] - ref["batch"])) <= 1e-12 * np.max(np.abs(ref["batch"]))
+    if not parallel:
+        assert np.array_equal(o["ibatch"], ref["ibatch"])
+    assert 0.05 < np.nanmean(o["acceptx"]) < 0.98
+    # device Philox: same draws in the same order as the one-wavefront-per-ensemble kernel
+    a = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=parallel, seed=77, outfun=outfun, _path=abi.PATH_TMFMA)
+    b = api.temper(tg, init, nb, nbatch, blen, nspac, scale, parallel=parallel, seed=77, outfun=outfun, _path=abi.PATH_LDS)
+    assert np.array_equal(a["final"], b["final"])
+    assert np.array_equal(np.nan_to_num(a["accepti"]), np.nan_to_num(b["accepti"]))
+    assert np.max(np.abs(a["batch"] - b["batch"])) <= 1e-12 * np.max(np.abs(b["batch"]))
+    # a restart continues the stream (tests/saveseed.R contract): two halves == one run
+    h1 = api.temper(tg, init, nb, nbatch // 2, blen, nspac, scale, parallel=parallel, seed=77, outfun=outfun, _path=abi.PATH_TMFMA)
+    h2 = api.temper(h1, _path=abi.PATH_TMFMA)
+    assert np.array_equal(h2["final"], a["final"])
