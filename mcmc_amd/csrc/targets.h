@@ -115,8 +115,36 @@ __device__ __forceinline__ void logistic_terms(const TargetView &t, const double
 #pragma unroll
         for (int j = 0; j < D; j++) vr[j] = v[j];
     }
-    // (staged in LDS: a few thousand rows at most, 32-bit loop control; and the sum starts from the first product
-    // instead of 0 + it, which differs only in the sign of a zero eta)
+    if constexpr (FOLD && D > 0) {
+        // The latency-bound case (C2: 6-7 rows per lane, one wavefront per SIMD): blocks of 4 rows per lane, fully
+        // unrolled with a uniform trip count, so that the rows' LDS reads, eta chains and table reads overlap -- a loop
+        // unrolled by 4 with a one-row remainder loop ran the last 3 of 7 rows one after the other, each paying its two
+        // LDS round trips and its dependent chain alone (30.8 -> 29.8 ms at C2; blocks of 8 have 24 table reads in
+        // flight, more than lgkmcnt counts: 37.9 ms).  Rows past n are clamped for the reads and contribute + 0.0 (the
+        // lane's sum is the same bits as before).  The sum starts from the first product instead of 0 + it, which
+        // differs only in the sign of a zero eta.
+        constexpr int U = 4;
+        const int nrow = (int)t.n;
+        for (int b0 = 0; b0 < nrow; b0 += U * G) {
+            double eta[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = b0 + g + u * G;
+                lds_cd *xli = xl + (size_t)(i < nrow ? i : nrow - 1) * D;
+                eta[u] = mul_nofma(xli[0], vr[0]);
+#pragma unroll
+                for (int j = 1; j < D; j++) eta[u] = add_nofma(eta[u], mul_nofma(xli[j], vr[j]));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double l1 = fmax(softplus_half_abs_lds_plain(eta[u], t.sp_shift) - 0.5 * fabs(eta[u]), 0.0);
+                const double term = fmin(eta[u], 0.0) - l1;
+                lp += (b0 + g + u * G < nrow) ? term : 0.0;
+            }
+        }
+        return;
+    }
+    // (staged in LDS: a few thousand rows at most, 32-bit loop control)
     typedef typename std::conditional<XL, int, long>::type idx_t;
     const idx_t nrow = (idx_t)t.n;
 #pragma unroll 4
@@ -124,11 +152,7 @@ __device__ __forceinline__ void logistic_terms(const TargetView &t, const double
         const double *xi = t.x + (size_t)i * d;
         lds_cd *xli = xl + (size_t)i * d;
         double eta = 0.0;
-        if (D > 0 && FOLD) {
-            eta = mul_nofma(xli[0], vr[0]);
-#pragma unroll
-            for (int j = 1; j < D; j++) eta = add_nofma(eta, mul_nofma(xli[j], vr[j]));
-        } else if (D > 0) {
+        if (D > 0) {
 #pragma unroll
             for (int j = 0; j < D; j++) eta = add_nofma(eta, mul_nofma(XL ? xli[j] : xi[j], vr[j]));
         } else {
@@ -177,7 +201,7 @@ template <int G> __device__ __forceinline__ double lud_group(const TargetView &t
         }
         for (int j = g; j < d; j += G) ss += v[j] * v[j];
         lp = group_sum<G>(lp);
-        lq = group_sum<G>(lq);
+        if (!(tab && t.xy_in_lds)) lq = group_sum<G>(lq);      // (the folded path puts every term into lp: lq is 0)
         ss = group_sum<G>(ss);
         return (lp + lq) - ss * t.prior_c;
     }
