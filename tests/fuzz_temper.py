@@ -63,8 +63,11 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     unif, norm = rng.random((E, niter, 4)), rng.standard_normal((E, niter, p))
     ref = oracle.temper(oracle.Target(K, p, **kw), init, nb, nbatch, blen, nspac, scale, parallel=parallel,
                         unif=unif, norm=norm, debug=debug, out_kind=out_kind)
+    # the model-selection posterior without a trace also runs with the ensembles in lockstep and the densities on the
+    # matrix cores (temper_mfma.hip): half of those cases take that path
+    tpath = abi.PATH_TMFMA if (kind == "models" and not debug and rng.integers(2)) else 0
     o = api.temper(api.Target(K, p, **kw), init, nb, nbatch, blen, nspac, scale, parallel=parallel, unif=unif,
-                   norm=norm, debug=debug, outfun=outfun)
+                   norm=norm, debug=debug, outfun=outfun, _path=tpath)
     ok = np.array_equal(o["final"], ref["final"]) and np.array_equal(o["acceptx"], ref["acceptx"], equal_nan=True)
     ok &= np.array_equal(o["accepti"], ref["accepti"], equal_nan=True)
     ok &= np.allclose(o["batch"], ref["batch"], rtol=1e-13, atol=1e-15)
@@ -89,7 +92,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
                 why.append("log.hastings %.3g" % np.nanmax(np.abs(o["log.hastings"] - ref["log.hastings"])))
     bad += not ok
     print("%-8s k=%d p=%d E=%d %s dbg=%d nb=%d bl=%d ns=%d scale=%s out=%s %s"
-          % (kind, k, p, E, "par" if parallel else "ser", debug, nbatch, blen, nspac, sk, outfun, "ok" if ok else "MISMATCH %s <<<<<<" % why),
+          % (kind + ("/mfma" if tpath else ""), k, p, E, "par" if parallel else "ser", debug, nbatch, blen, nspac, sk, outfun, "ok" if ok else "MISMATCH %s <<<<<<" % why),
           flush=True)
 print("bad", bad)
 sys.exit(1 if bad else 0)
