@@ -369,6 +369,13 @@ int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean);
 int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mean, double *var,
                  int32_t nocalc, int device_ptrs);
 
+/* Host-only diagnostic (no counterpart in the reference, no GPU call): builds the work plan olbm uses for windows of
+ * >= 1024 rows (olbm_comb.hip: teeth one window length apart swept together, split over `groups` workgroups) and checks
+ * it -- every window in exactly one piece, pieces in time order without gaps, step counts consistent.  Returns the
+ * number of violations (0 = sound; -1: bad argument). */
+int mcmchip_olbm_comb_plan_check(int64_t nwin, int64_t len, int32_t teeth, int64_t groups, int32_t *npieces,
+                                 int64_t *min_steps, int64_t *max_steps);
+
 /* Cross-chain diagnostics -- NO COUNTERPART IN THE REFERENCE, which runs one chain (its users read colMeans(out$batch)
  * and apply(out$batch, 2, sd) / sqrt(out$nbatch), vignettes/demo.Rnw:210-222).  A batched call returns nchain x nbatch x
  * nout batch means (mcmchip_metrop_out.batch); this reduces them over chains, per output functional j:

@@ -153,6 +153,7 @@ EXPORTS = [
     "mcmchip_metrop_multi",
     "mcmchip_temper_multi",
     "mcmchip_initseq",
+    "mcmchip_olbm_comb_plan_check",
     "mcmchip_lagsums",
     "mcmchip_initseq_from_lagsums",
     "mcmchip_olbm",

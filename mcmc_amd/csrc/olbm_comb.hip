@@ -567,6 +567,56 @@ static void plan_combs(long nwin, long len, int teeth, long groups, CombPlan &pl
     }
 }
 
+// Host-only check of the plan (no GPU call; tests/test_host_cpu.py): every window of [0, nwin) must belong to exactly one
+// (comb, tooth), the pieces must be numbered in time order and tile [0, nwin) without gaps, and the workgroups' step
+// counts must be balanced.  Returns the number of violations; reports the piece count and the step range.
+extern "C" int mcmchip_olbm_comb_plan_check(int64_t nwin, int64_t len, int32_t teeth, int64_t groups, int32_t *npieces,
+                                            int64_t *min_steps, int64_t *max_steps)
+{
+    if (nwin < 1 || len < 1 || teeth < 1 || groups < 1) return -1;
+    CombPlan pl;
+    plan_combs((long)nwin, (long)len, teeth, (long)groups, pl);
+    long bad = 0;
+    std::vector<unsigned char> seen((size_t)nwin, 0);
+    std::vector<long> pstart((size_t)pl.npieces, -1);
+    for (size_t ci = 0; ci < pl.combs.size(); ci++) {
+        const OlbmComb &c = pl.combs[ci];
+        if (c.m < 1 || c.m > teeth || c.rlen < 1) bad++;
+        for (int k = 0; k < c.m; k++) {
+            const int j = c.piece0 + k * c.pstride;
+            if (j < 0 || j >= pl.npieces) { bad++; continue; }
+            if (pstart[(size_t)j] != -1 || pl.pcnt[(size_t)j] != c.rlen) bad++;
+            pstart[(size_t)j] = c.base + (long)k * len;
+            if ((pl.ptile[(size_t)j] != 0) != (pstart[(size_t)j] % len == 0)) bad++;
+            for (int r = 0; r < c.rlen; r++) {
+                const long w = c.base + (long)k * len + r;
+                if (w < 0 || w >= nwin || seen[(size_t)w]) bad++;
+                else seen[(size_t)w] = 1;
+            }
+        }
+    }
+    for (long w = 0; w < nwin; w++) bad += !seen[(size_t)w];
+    long at = 0;                                            // pieces in time order, contiguous
+    for (int j = 0; j < pl.npieces; j++) {
+        if (pstart[(size_t)j] != at) bad++;
+        at = pstart[(size_t)j] + pl.pcnt[(size_t)j];
+    }
+    if (at != nwin) bad++;
+    long lo = -1, hi = 0;
+    if (pl.first.size() != pl.steps.size() + 1 || pl.first.back() != (int)pl.combs.size()) bad++;
+    for (size_t g = 0; g < pl.steps.size(); g++) {
+        long st = 0;
+        for (int ci = pl.first[g]; ci < pl.first[g + 1]; ci++) st += (long)pl.combs[(size_t)ci].m * ((pl.combs[(size_t)ci].rlen + OM_SLAB - 1) / OM_SLAB);
+        if (st != pl.steps[g]) bad++;
+        if (lo < 0 || st < lo) lo = st;
+        if (st > hi) hi = st;
+    }
+    if (npieces) *npieces = pl.npieces;
+    if (min_steps) *min_steps = lo;
+    if (max_steps) *max_steps = hi;
+    return (int)(bad > 0x7fffffff ? 0x7fffffff : bad);
+}
+
 bool olbm_comb_applies(long n, int p, long len)
 {
     static const char *env = getenv("MCMCHIP_OLBM_COMB");

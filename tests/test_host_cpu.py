@@ -275,3 +275,27 @@ def test_plain_c_client_builds():
     ex = os.path.join(ROOT, "examples")
     subprocess.check_call(["make", "-s", "-B", "-C", ex])
     assert os.access(os.path.join(ex, "capi_demo"), os.X_OK)
+
+
+def test_olbm_comb_plan_covers_every_window_once():
+    """The host-side plan of olbm_comb.hip (teeth one window length apart swept together, split over the workgroups, pieces
+    chained afterwards) is pure host code: every window of [0, nwin) in exactly one piece, pieces in time order without
+    gaps, step counts consistent and balanced -- over random shapes and the C5 shape.  No GPU call."""
+    import ctypes as C
+    from mcmc_amd import api
+    f = api.load_library().mcmchip_olbm_comb_plan_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(3)
+    npieces, lo, hi = C.c_int32(), C.c_int64(), C.c_int64()
+    cases = [(99_990_257, 10_000, 5, 256), (17, 16, 5, 256), (1, 1, 1, 1), (33, 16, 8, 3), (4097, 1024, 5, 512), (2_000_001, 1_000_000, 5, 256)]
+    for _ in range(300):
+        ln = int(rng.choice([1, 2, 15, 16, 17, 31, 100, 1024, 1027, 4096]))
+        nwin = int(rng.integers(1, 60)) * ln + int(rng.integers(0, ln))
+        cases.append((max(nwin, 1), ln, int(rng.integers(1, 9)), int(rng.choice([1, 2, 7, 256, 1024]))))
+    for nwin, ln, teeth, groups in cases:
+        assert f(nwin, ln, teeth, groups, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0, (nwin, ln, teeth, groups)
+        assert npieces.value >= -(-nwin // ln)
+    assert f(99_990_257, 10_000, 5, 256, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0
+    # C5: the busiest of the 256 workgroups is within one comb step (5 slabs) of the mean
+    assert hi.value <= -(-99_990_257 // (16 * 256)) + 5 and 10_000 <= npieces.value <= 12_000
