@@ -621,10 +621,15 @@ bool olbm_comb_applies(long n, int p, long len)
 {
     static const char *env = getenv("MCMCHIP_OLBM_COMB");
     if (env && env[0] == '0') return false;
+    // Measured at n = 1e8, len = 1e4 (ms, comb / two-stream kernel): p = 256: 113.6 / 128.3, p = 128: 45.2 / 49.2,
+    // p = 64: 21.2 / 21.9, p = 32: 19.9 / 15.5 -- for few columns neither kernel is near the HBM rate (the producer, built
+    // for 256 columns, is what takes the time) and the comb's extra bookkeeping loses.  MCMCHIP_OLBM_COMB=<min len>
+    // lowers the window threshold and takes every p <= 256 (tests/fuzz_olbm_comb.py).
     long min_len = 1024;
-    if (env && atol(env) > 1) min_len = atol(env);
+    int min_p = 65;
+    if (env && atol(env) > 1) { min_len = atol(env); min_p = 1; }
     const long nwin = n - len + 1;
-    return p <= 256 && len >= min_len && nwin >= 2 * len && 8 * (4 * n + len + 64) < (1L << 32);
+    return p >= min_p && p <= 256 && len >= min_len && nwin >= 2 * len && 8 * (4 * n + len + 64) < (1L << 32);
 }
 
 // what a finish step needs from the walk (kept so that the finish can be repeated about another centre)
