@@ -358,6 +358,8 @@ int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean);
  * nocalc != 0: `mean` is input (used as given); nocalc == 0: means computed and returned (for n >= 2^20 and p <= 256
  * in the same pass over x as the matrix, not in a pass of their own as in olbm.c:38-43; they come out correctly
  * rounded to an ulp, where the reference's sequential sum is good to ~sqrt(n) ulp).
+ * p <= 8 runs as a stream on the vector units (olbm_small.hip: 0.4 - 5 ms per 1e8 rows; MCMCHIP_OLBM_SMALL=0 keeps the
+ * matrix-core kernel).
  * Windows of >= 1024 rows (64 < p <= 256, at least two window lengths of windows) are computed with x read once instead of
  * twice (olbm_comb.hip; MCMCHIP_OLBM_COMB=0 keeps the two-stream kernel).
  * Accuracy, stated here because it is a deviation a caller should know: the device agrees with an 80-bit evaluation

@@ -362,6 +362,13 @@ __global__ __launch_bounds__(256) void olbm_s0_kernel(const double *__restrict__
     }
 }
 
+int olbm_first_window_sums(const double *x, long n, int p, long len, const double *dcentre, double *s0, double *tail, hipStream_t s)
+{
+    hipLaunchKernelGGL(olbm_s0_kernel, dim3((unsigned)p), dim3(256), 0, s, x, n, len, n / len, dcentre, s0, tail);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
 // pieces in time order: s_{j+1} = s_j + e_j.  Two levels: sums of chunks of pieces, then every chunk rewrites its e_j as the
 // exclusive prefix E_j (window sum at the piece's start less the one at window 0) and sums the E_j of the pieces that
 // start a tooth (windows at multiples of len).  thread = column

@@ -47,3 +47,9 @@ int olbm_exact_means(const double *x, long n, int p, double *dmean, hipStream_t 
 bool olbm_comb_applies(long n, int p, long len);
 struct DeviceCtx;
 int run_olbm_comb(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc);
+// olbm_comb.hip: s0[c] = sum over the first window of (x - centre), tail[c] = the same over the rows after the last window
+// that starts at a multiple of len
+int olbm_first_window_sums(const double *x, long n, int p, long len, const double *dcentre, double *s0, double *tail, hipStream_t s);
+// olbm_small.hip: p <= 8 on the vector units
+bool olbm_small_applies(long n, int p, long len);
+int run_olbm_small(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc);
