@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/rN_pmc_traffic.json from the FETCH_SIZE and WRITE_SIZE passes of tools/bench_profile.sh, stamped with the hash
 of the kernel's sources (tools/kernel_source_hash.py) so that bench.py quotes it only for the kernel it was measured on.
-usage: python tools/make_traffic_record.py <benchprof dir> > profiles/r3_pmc_traffic.json"""
+usage: python tools/make_traffic_record.py <benchprof dir | prefix of the <prefix>_{fetch,write,stats}.json summaries that
+tools/pmc_summary.py wrote on the box> > profiles/r3_pmc_traffic.json"""
 import json
 import os
 import sys
@@ -13,9 +14,12 @@ from pmc_summary import summarize  # noqa: E402
 
 d = sys.argv[1]
 n, dim, chains = 1000000, 64, 65536
-fetch = summarize(os.path.join(d, "fetch"), "logdens_mfma_kernel")
-write = summarize(os.path.join(d, "write"), "logdens_mfma_kernel")
-stats = summarize(os.path.join(d, "stats"), "logdens_mfma_kernel")
+if os.path.isdir(d):
+    fetch = summarize(os.path.join(d, "fetch"), "logdens_mfma_kernel")
+    write = summarize(os.path.join(d, "write"), "logdens_mfma_kernel")
+    stats = summarize(os.path.join(d, "stats"), "logdens_mfma_kernel")
+else:
+    fetch, write, stats = (json.load(open("%s_%s.json" % (d, k))) for k in ("fetch", "write", "stats"))
 fkb = fetch["per_launch_counters"]["FETCH_SIZE"]
 wkb = write["per_launch_counters"]["WRITE_SIZE"]
 nunits = 254
