@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (BASELINE configs 2, 4 and 5 on the device; N = 1 only)")
-    ap.add_argument("--secondary", default="c2,c4,c5", help="which secondary configs to run")
+    ap.add_argument("--secondary", default="c2,c4,c5,temper_models", help="which secondary configs to run")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the collectives go through "
                          "gloo on host copies (RCCL refuses two ranks on one device); exercises the sharding, not the fabric")

@@ -148,16 +148,58 @@ def c5(api, torch, dev, n=100_000_256, p=256, blen=10_000):
                                  "hbm_algorithmic_TBs": 8.0 * n * p / (kms * 1e-3) / 1e12},
                     "var_diag_over_theory": [float(var[c, c] * n / ((1 / (1 - r * r)) * (1 + r) / (1 - r))) for c, r in
                                               ((0, 0.5), (p - 1, 0.99))]})
+    # the usual call has a handful of functionals: the first 3 and the first 8 columns of the same series (olbm_small.hip)
+    for pp in (3, 8):
+        m2, v2 = np.zeros(pp), np.empty((pp, pp))
+        for rep in range(2):
+            t0 = time.perf_counter()
+            rc = L.mcmchip_olbm(x.data_ptr(), n, pp, blen, m2.ctypes.data, v2.ctypes.data, 0, 1)
+            el = time.perf_counter() - t0
+            if rc:
+                raise RuntimeError(L.mcmchip_last_error().decode())
+        kn, kms, _ = api.last_kernel_time()
+        res.append({"workload": "olbm n=%d p=%d len=%d (few functionals), means computed in the same pass" % (n, pp, blen),
+                    "seconds": el, "kernel": kn, "kernel_ms": kms,
+                    "roofline": {"bound": "hbm", "achieved": 8.0 * n * pp / (kms * 1e-3) / 1e12, "peak": PEAK_HBM_TBS, "unit": "TB/s",
+                                 "frac": 8.0 * n * pp / (kms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                                 "note": "algorithmic bytes = the series once; the kernel reads x[t+len] and x[t]"},
+                    "var_diag_over_theory": [float(v2[0, 0] * n / ((1 / (1 - 0.25)) * 3.0))]})
     del x
     torch.cuda.empty_cache()
     return res
 
 
-def run(api, torch, dev, which=("c2", "c4", "c5")):
+def temper_models(api):
+    """Tempering over the 8 sub-models of tests/temp-par.R on a synthetic data set of 262 144 rows: the ensembles in
+    lockstep, log densities on the matrix cores (temper_mfma.hip)."""
+    from mcmc_amd import abi
+    rng = np.random.default_rng(0)
+    n, p, k, E, niter = 262144, 4, 8, 1024, 200
+    masks = np.array([[1, a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=float)
+    nb = np.array([[np.sum(masks[i] != masks[j]) == 1 for j in range(k)] for i in range(k)])
+    X = rng.standard_normal((n, p)) / 2
+    X[:, 0] = 1.0
+    beta = np.array([0.3, 0.5, -0.4, 0.2])
+    y = (rng.random(n) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    tg = api.Target(abi.T_LOGISTIC_MODELS, p, x=X, y=y, prior_c=0.125, par=abi.logistic_models_par(masks))
+    init = np.tile(beta, (E, k, 1))
+    api.temper(tg, init, nb, 2, 1, 1, 2.0 / np.sqrt(n), parallel=True, seed=1)
+    t0 = time.perf_counter()
+    o = api.temper(tg, init, nb, niter, 1, 1, 2.0 / np.sqrt(n), parallel=True, seed=1)
+    el = time.perf_counter() - t0
+    kn, kms, nl = api.last_kernel_time()
+    return {"workload": "parallel tempering over 8 logistic sub-models (temp-par.R) on n=%d rows, %d ensembles x %d iterations" % (n, E, niter),
+            "kernel": kn, "kernel_ms_per_iteration": kms, "ms_per_iteration_end_to_end": el / niter * 1e3,
+            "softplus_values_per_s": 2.0 * E * n / (kms * 1e-3), "acceptx_mean": float(np.nanmean(o["acceptx"])),
+            "bound": "vector epilogue of the density kernel (d = 4: 9 instructions per softplus value on the pipe the MFMAs share)"}
+
+
+def run(api, torch, dev, which=("c2", "c4", "c5", "temper_models")):
     out = {}
     for w in which:
         try:
-            out[w] = {"c2": lambda: c2(api), "c4": lambda: c4(api), "c5": lambda: c5(api, torch, dev)}[w]()
+            out[w] = {"c2": lambda: c2(api), "c4": lambda: c4(api), "c5": lambda: c5(api, torch, dev),
+                      "temper_models": lambda: temper_models(api)}[w]()
         except Exception as e:                   # a secondary number never takes the headline line down
             out[w] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
