@@ -360,6 +360,9 @@ int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean);
  * rounded to an ulp, where the reference's sequential sum is good to ~sqrt(n) ulp).
  * p <= 8 runs as a stream on the vector units (olbm_small.hip: 0.4 - 5 ms per 1e8 rows; MCMCHIP_OLBM_SMALL=0 keeps the
  * matrix-core kernel).
+ * 5 <= p <= 64 with windows of >= 256 rows (at least four window lengths of windows; p <= 8 only from 2e6 rows on) runs on
+ * the matrix cores with one lane per (tooth, column) and no scan (olbm_lane.hip: 2 - 16 ms per 1e8 rows, 1.25 x the input
+ * read; MCMCHIP_OLBM_LANE=0 keeps the kernels that served before).
  * Windows of >= 1024 rows (64 < p <= 256, at least two window lengths of windows) are computed with x read once instead of
  * twice (olbm_comb.hip; MCMCHIP_OLBM_COMB=0 keeps the two-stream kernel).
  * Accuracy, stated here because it is a deviation a caller should know: the device agrees with an 80-bit evaluation
@@ -377,6 +380,10 @@ int mcmchip_olbm(const double *x, int64_t n, int32_t p, int64_t len, double *mea
  * number of violations (0 = sound; -1: bad argument). */
 int mcmchip_olbm_comb_plan_check(int64_t nwin, int64_t len, int32_t teeth, int64_t groups, int32_t *npieces,
                                  int64_t *min_steps, int64_t *max_steps);
+/* The same check for the plan of olbm_lane.hip (four teeth per wave, units of the sweep dealt round-robin to `groups`
+ * workgroups).  Host-only, no counterpart in the reference. */
+int mcmchip_olbm_lane_plan_check(int64_t nwin, int64_t len, int64_t groups, int32_t *npieces, int64_t *min_steps,
+                                 int64_t *max_steps);
 
 /* Cross-chain diagnostics -- NO COUNTERPART IN THE REFERENCE, which runs one chain (its users read colMeans(out$batch)
  * and apply(out$batch, 2, sd) / sqrt(out$nbatch), vignettes/demo.Rnw:210-222).  A batched call returns nchain x nbatch x

@@ -26,14 +26,6 @@
 #include <type_traits>
 #include <vector>
 
-struct OlbmComb {
-    long base;          // first window of tooth 0
-    int m;              // teeth, len windows apart
-    int rlen;           // windows per tooth in this comb (the sweep)
-    int piece0;         // piece of tooth k: piece0 + k * pstride (pieces are numbered in time order)
-    int pstride;
-};
-
 template <int F> struct CombShape {
     using S = OmShape<F>;
     static constexpr int M = F == 16 ? 5 : 8;            // teeth whose state fits beside the window-sum image
@@ -380,8 +372,31 @@ __global__ __launch_bounds__(256) void olbm_chain_sum_kernel(const double *__res
     if (col >= PP) return;
     const int j1 = j0 + OC_CHUNK < npieces ? j0 + OC_CHUNK : npieces;
     double s = 0.0;
+#pragma unroll 16
     for (int j = j0; j < j1; j++) s += pe[(size_t)j * PP + col];
     csum[(size_t)blockIdx.x * PP + col] = s;
+}
+
+// csum[chunk][col] -> its exclusive prefix over the chunks, in place.  One workgroup: 256 / PP threads per column, each over
+// a run of chunks (a prefix per chunk by every chunk's own workgroup was quadratic: 3000 chunks of pieces took 0.5 ms)
+__global__ __launch_bounds__(256) void olbm_chain_scan_kernel(double *__restrict__ csum, int nchunk, int PP)
+{
+    __shared__ double part[256];
+    const int t = threadIdx.x, col = t % PP, seg = t / PP, nseg = 256 / PP;      // threads beyond nseg * PP find no chunks
+    const int per = (nchunk + nseg - 1) / nseg, c0 = seg * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
+    double sm = 0.0;
+#pragma unroll 16
+    for (int c = c0; c < c1; c++) sm += csum[(size_t)c * PP + col];
+    part[t] = sm;
+    __syncthreads();
+    double E = 0.0;
+    for (int k = 0; k < seg; k++) E += part[k * PP + col];
+#pragma unroll 16
+    for (int c = c0; c < c1; c++) {
+        const double v = csum[(size_t)c * PP + col];
+        csum[(size_t)c * PP + col] = E;
+        E += v;
+    }
 }
 
 __global__ __launch_bounds__(256) void olbm_chain_prefix_kernel(double *__restrict__ pe, const unsigned char *__restrict__ ptile,
@@ -391,8 +406,8 @@ __global__ __launch_bounds__(256) void olbm_chain_prefix_kernel(double *__restri
     const int col = threadIdx.x, j0 = blockIdx.x * OC_CHUNK;
     if (col >= PP) return;
     const int j1 = j0 + OC_CHUNK < npieces ? j0 + OC_CHUNK : npieces;
-    double E = 0.0, ts = 0.0;
-    for (int c = 0; c < (int)blockIdx.x; c++) E += csum[(size_t)c * PP + col];
+    double E = csum[(size_t)blockIdx.x * PP + col], ts = 0.0;   // exclusive prefix over the chunks (olbm_chain_scan_kernel)
+#pragma unroll 16
     for (int j = j0; j < j1; j++) {
         const double e = pe[(size_t)j * PP + col];
         pe[(size_t)j * PP + col] = E;
@@ -410,19 +425,55 @@ __global__ __launch_bounds__(256) void olbm_chain_mean_kernel(const double *__re
                                                               int want_mean, double *__restrict__ mean,
                                                               double *__restrict__ delta, double *__restrict__ shift)
 {
+    // the chunks' sums: 256 / PP threads per column over runs of chunks, then in run order (one thread per column walking
+    // 1700 chunks took half a millisecond)
+    __shared__ double part[256];
+    {
+        const int t = threadIdx.x, pc = t % PP, seg = t / PP, nseg = 256 / PP;
+        const int per = (nchunk + nseg - 1) / nseg, c0 = seg * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
+        double sm = 0.0;
+        if (want_mean) {
+#pragma unroll 16
+            for (int c = c0; c < c1; c++) sm += tsum[(size_t)c * PP + pc];
+        }
+        part[t] = sm;
+    }
+    __syncthreads();
     const int col = threadIdx.x;
     if (col >= PP) return;
     if (col >= p) { shift[col] = 0.0; return; }
     double d = 0.0;
     if (want_mean) {
         double ts = 0.0;
-        for (int c = 0; c < nchunk; c++) ts += tsum[(size_t)c * PP + col];
+        for (int k = 0; k < 256 / PP; k++) ts += part[k * PP + col];
         const double nd = ((double)ntile * s0[col] + ts) + tail[col];
         d = nd / (double)n;
         mean[col] = centre[col] + d;                                   // olbm.c:42
         delta[col] = d;
     }
     shift[col] = s0[col] - (double)len * d;
+}
+
+// the three chain steps for callers outside this file (olbm_lane.hip)
+int olbm_chain_pieces(double *pe, const unsigned char *ptile, int npieces, int PP, double *csum, double *tsum, hipStream_t s)
+{
+    const int nchunk = (npieces + OC_CHUNK - 1) / OC_CHUNK;
+    hipLaunchKernelGGL(olbm_chain_sum_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, pe, npieces, PP, csum);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(olbm_chain_scan_kernel, dim3(1), dim3(256), 0, s, csum, nchunk, PP);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(olbm_chain_prefix_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, pe, ptile, npieces, PP, csum, tsum);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+int olbm_chain_chunks(int npieces) { return (npieces + OC_CHUNK - 1) / OC_CHUNK; }
+int olbm_chain_means(const double *tsum, int nchunk, int PP, int p, const double *s0, const double *tail, const double *centre,
+                     long n, long len, int want_mean, double *mean, double *delta, double *shift, hipStream_t s)
+{
+    hipLaunchKernelGGL(olbm_chain_mean_kernel, dim3(1), dim3(256), 0, s, tsum, nchunk, PP, p, s0, tail, centre, n, len, n / len,
+                       want_mean, mean, delta, shift);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
 }
 
 // rank-two terms: sum_j cnt_j sig_j sig_j^T + sig_j d_j^T + d_j sig_j^T for the tile (w, q) of olbm_comb_kernel's
@@ -489,18 +540,10 @@ __global__ __launch_bounds__(256) void olbm_comb_finish_kernel(const double *__r
 // ---------------------------------------------------------------------------------------------
 // host: the plan (combs per workgroup, pieces in time order) and the launches
 // ---------------------------------------------------------------------------------------------
-struct CombPlan {
-    std::vector<OlbmComb> combs;
-    std::vector<int> first, steps, pcnt;
-    std::vector<unsigned char> ptile;
-    int npieces = 0;
-    long max_steps = 0;
-};
-
 // teeth t = 0 .. Q-1 of len windows (tooth t starts at window t * len) and one of nwin % len; super-blocks of up to
 // `teeth` consecutive full teeth are swept together; the (super-block, sweep position) axis is cut into `groups` shares
 // of equal step count at multiples of 16 sweep positions
-static void plan_combs(long nwin, long len, int teeth, long groups, CombPlan &pl)
+void plan_combs(long nwin, long len, int teeth, long groups, CombPlan &pl)
 {
     struct SB { long tooth0; int m; long R; };
     std::vector<SB> sbs;
@@ -577,12 +620,8 @@ static void plan_combs(long nwin, long len, int teeth, long groups, CombPlan &pl
 // Host-only check of the plan (no GPU call; tests/test_host_cpu.py): every window of [0, nwin) must belong to exactly one
 // (comb, tooth), the pieces must be numbered in time order and tile [0, nwin) without gaps, and the workgroups' step
 // counts must be balanced.  Returns the number of violations; reports the piece count and the step range.
-extern "C" int mcmchip_olbm_comb_plan_check(int64_t nwin, int64_t len, int32_t teeth, int64_t groups, int32_t *npieces,
-                                            int64_t *min_steps, int64_t *max_steps)
+int olbm_plan_violations(const CombPlan &pl, long nwin, long len, int teeth, int *npieces, long *min_steps, long *max_steps)
 {
-    if (nwin < 1 || len < 1 || teeth < 1 || groups < 1) return -1;
-    CombPlan pl;
-    plan_combs((long)nwin, (long)len, teeth, (long)groups, pl);
     long bad = 0;
     std::vector<unsigned char> seen((size_t)nwin, 0);
     std::vector<long> pstart((size_t)pl.npieces, -1);
@@ -622,6 +661,19 @@ extern "C" int mcmchip_olbm_comb_plan_check(int64_t nwin, int64_t len, int32_t t
     if (min_steps) *min_steps = lo;
     if (max_steps) *max_steps = hi;
     return (int)(bad > 0x7fffffff ? 0x7fffffff : bad);
+}
+
+extern "C" int mcmchip_olbm_comb_plan_check(int64_t nwin, int64_t len, int32_t teeth, int64_t groups, int32_t *npieces,
+                                            int64_t *min_steps, int64_t *max_steps)
+{
+    if (nwin < 1 || len < 1 || teeth < 1 || groups < 1) return -1;
+    CombPlan pl;
+    plan_combs((long)nwin, (long)len, teeth, (long)groups, pl);
+    long lo = 0, hi = 0;
+    const int bad = olbm_plan_violations(pl, (long)nwin, (long)len, teeth, npieces, &lo, &hi);
+    if (min_steps) *min_steps = lo;
+    if (max_steps) *max_steps = hi;
+    return bad;
 }
 
 bool olbm_comb_applies(long n, int p, long len)
@@ -753,11 +805,7 @@ static int launch_olbm_comb(const double *x, long n, int p, long len, const doub
     HIP_TRY(hipGetLastError());
     // e_j -> E_j in place (once: a repeat of the finish about another centre reuses them)
     double *csum = K.small, *tsum = csum + (size_t)nchunk * S::PP;
-    hipLaunchKernelGGL(olbm_chain_sum_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, K.pe, np, S::PP, csum);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(olbm_chain_prefix_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, K.pe, dptile, np, S::PP,
-                       csum, tsum);
-    HIP_TRY(hipGetLastError());
+    if (int rc = olbm_chain_pieces(K.pe, dptile, np, S::PP, csum, tsum, s)) return rc;
     return finish_olbm_comb<F>(x, n, p, len, dcentre, dmean_out, ddelta, dvar, dc, keep);
 }
 

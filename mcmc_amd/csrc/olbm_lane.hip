@@ -1,0 +1,533 @@
+// olbm_lane.hip -- olbm() (reference olbm.c:22-78) for 9 .. 64 columns and long windows: a wave walks FOUR TEETH of a comb
+// with one lane per (tooth, column), and nothing is scanned.
+//
+// v_mfma_f64_16x16x4_f64 takes a 16 x 4 operand: lane l supplies element (column l % 16, k = l / 16).  olbm_mfma_kernel
+// and olbm_comb_kernel fill k with four CONSECUTIVE windows, which is why they need a producer: window sums of 16
+// consecutive windows are a prefix scan of the differences x[t + len] - x[t] (olbm.c:61-62), across lanes.  But the sum
+// over windows of (window sum)(window sum)^T does not care which four windows share an instruction.  Here k is the
+// TOOTH: lane (j, c) walks the windows  base + j * len + i,  i = 0, 1, 2, ...  of column c one after another, its window
+// sum is a running sum in a register (D += x[t + len] - x[t]: one add per step, no scan, no cross-lane traffic), and the
+// four teeth are len apart, so the row tooth j adds is the row tooth j + 1 drops: a chunk of T steps needs five rows
+// per column for four teeth -- 1.25 x the input instead of 2 x (the comb of olbm_comb.hip, for free).
+//
+// As there, D is relative to the (unknown) window sum s at the start of a piece (a run of windows of one tooth):
+//     sum_w (s + D_w)(s + D_w)^T = sum_w D_w D_w^T  +  cnt s s^T + s d^T + d s^T,        d = sum_w D_w,
+// the matrix cores accumulate sum D D^T, a lane keeps d and the piece's last D (e), and the pieces are chained
+// afterwards from one direct sum per column (olbm_comb.hip's chain kernels, shared); the exact means (olbm.c:38-43) come
+// out of the chain too.
+//
+// Memory: a wave loads whole 64 .. 256-byte runs of a column (coalesced, [column][time]), keeps the NEXT chunk in
+// registers while it works on the current one (80 VGPRs in flight per lane: 20 KB per wave, 160 KB per CU), takes the
+// differences in that layout, and turns them to [tooth][column] through a wave-private piece of LDS (odd pitch, no
+// bank conflicts, no workgroup barrier anywhere in the kernel).
+#include "kernels.h"
+#include "olbm_shape.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include <chrono>
+#include <stdio.h>
+#include <vector>
+
+namespace {
+
+template <int NB, int TT> struct LaneShape {
+    static constexpr int PP = 16 * NB;                              // padded columns
+    static constexpr int T = TT;                                    // steps per chunk
+    static constexpr int TP = T + 1;                                // LDS pitch of a (tooth, column) run: odd
+    static constexpr int SEG = 64 / T;                              // column runs per load instruction
+    static constexpr int KPR = 16 / SEG;                            // load instructions per tooth row (a wave loads 16 columns)
+    static constexpr int H = NB / 2;
+    static constexpr int NK = H + 1;                                // tiles of wave w: (w, (w + k) % NB), k = 0 .. H
+    static constexpr int NTT = NB * NK;                             // tile slots (the k = H slots of waves >= NB / 2 stay empty for even NB)
+    static constexpr size_t lds_bytes = (size_t)NB * 4 * 16 * TP * 8;
+    __host__ __device__ static constexpr bool tile_used(int w, int k) { return NB == 1 || k < H || NB % 2 == 1 || w < NB / 2; }
+};
+
+// A workgroup = one share of the plan; wave w loads the 16 columns of block w (five rows of T steps for four teeth),
+// the differences of all blocks meet in LDS, wave w accumulates the tiles (w, w), (w, w+1), .. (circulant: every unordered
+// pair of blocks once) from running sums of its own and the next H blocks.
+template <int NB, int TT>
+__global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__restrict__ x, long n, int p, long len,
+                                                            const OlbmComb *__restrict__ combs,
+                                                            const int *__restrict__ first, double *__restrict__ partial,
+                                                            double *__restrict__ pd, double *__restrict__ pe)
+{
+    using S = LaneShape<NB, TT>;
+    constexpr int T = S::T, TP = S::TP, SEG = S::SEG, KPR = S::KPR, PP = S::PP, NK = S::NK;
+    extern __shared__ double W[];                                   // [NB][4][16][TP]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int g = blockIdx.x;
+    const int j = lane >> 4, c = lane & 15;                         // the walk: tooth, column inside a block of 16
+    const int li = lane % T, lseg = lane / T;                       // the loads: step inside the chunk, column run
+    const bool full = S::tile_used(wave, NK - 1);                   // does this wave own a k = H tile
+
+    om_double4 acc[NK];
+#pragma unroll
+    for (int t = 0; t < NK; t++) acc[t] = om_double4{0.0, 0.0, 0.0, 0.0};
+    double D[NK], dsum = 0.0;
+#pragma unroll
+    for (int q = 0; q < NK; q++) D[q] = 0.0;
+
+    struct Cur { int ci, i0, m, rlen, piece0, pstride; long base; };
+    const int ci_end = __builtin_amdgcn_readfirstlane(first[g + 1]);
+    auto load_comb = [&](Cur &u) {
+        u.i0 = 0;
+        if (u.ci < ci_end) {
+            const OlbmComb *cb = combs + u.ci;
+            u.m = __builtin_amdgcn_readfirstlane(cb->m);
+            u.rlen = __builtin_amdgcn_readfirstlane(cb->rlen);
+            u.piece0 = __builtin_amdgcn_readfirstlane(cb->piece0);
+            u.pstride = __builtin_amdgcn_readfirstlane(cb->pstride);
+            const long b = cb->base;
+            u.base = ((long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+        } else {
+            u.m = 0;                                                // past the end: loads land where they did before, nothing is kept
+            u.rlen = 0;
+        }
+    };
+    auto advance = [&](Cur &u) {
+        u.i0 += T;
+        if (u.i0 >= u.rlen) {
+            u.ci++;
+            load_comb(u);
+        }
+    };
+
+    // the lane's columns in the loads, clamped into the matrix (what a clamped load returns is replaced by zero later)
+    size_t coloff[KPR];
+#pragma unroll
+    for (int k = 0; k < KPR; k++) {
+        const int col = 16 * wave + k * SEG + lseg;
+        coloff[k] = (size_t)(col < p ? col : p - 1) * (size_t)n;
+    }
+    double st[5][KPR];                                              // the chunk in flight: rows of tooth 0 .. 4
+    auto issue = [&](const Cur &u) {
+        const long tb = u.base + u.i0 + li;
+#pragma unroll
+        for (int jj = 0; jj < 5; jj++) {
+            long t = tb + jj * len;
+            t = t < n ? t : n - 1;
+#pragma unroll
+            for (int k = 0; k < KPR; k++) st[jj][k] = x[coloff[k] + t];
+        }
+    };
+    double *Wc = W + (size_t)wave * 64 * TP + li;                   // commit: block = wave
+    auto commit = [&](const Cur &u) {
+        const long tb = u.base + u.i0 + li;
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) {
+            const bool okd = jt < u.m && tb + (jt + 1) * len < n;   // the last window of the series adds nothing (olbm.c:60)
+#pragma unroll
+            for (int k = 0; k < KPR; k++) {
+                const int cc = k * SEG + lseg;
+                const double del = okd && 16 * wave + cc < p ? st[jt + 1][k] - st[jt][k] : 0.0;
+                Wc[(jt * 16 + cc) * TP] = del;
+            }
+        }
+    };
+    auto sync = [&]() {
+        if constexpr (NB == 1) {                                    // one wave: LDS operations complete in order
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else __syncthreads();
+    };
+
+    Cur cur;
+    cur.ci = __builtin_amdgcn_readfirstlane(first[g]);
+    cur.base = 0;
+    cur.m = cur.rlen = cur.piece0 = cur.pstride = 0;
+    load_comb(cur);
+    issue(cur);
+    const double *Wr[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) Wr[k] = W + (size_t)((wave + k) % NB) * 64 * TP + (j * 16 + c) * TP;
+    auto step = [&](const double (&d)[NK], auto fullc) {
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            if (k < NK - 1 || NK == 1 || decltype(fullc)::value)
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], D[k], acc[k], 0, 0, 0);
+        dsum += D[0];
+#pragma unroll
+        for (int k = 0; k < NK; k++) D[k] += d[k];
+    };
+    auto walk = [&](int nst, auto fullc) {
+        int i = 0;
+        for (; i + 4 <= nst; i += 4) {
+            double d[4][NK];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int k = 0; k < NK; k++) d[u][k] = Wr[k][i + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) step(d[u], fullc);
+        }
+        for (; i < nst; i++) {
+            double d[NK];
+#pragma unroll
+            for (int k = 0; k < NK; k++) d[k] = Wr[k][i];
+            step(d, fullc);
+        }
+    };
+    while (cur.ci < ci_end) {
+        commit(cur);
+        sync();
+        Cur nxt = cur;
+        advance(nxt);
+        issue(nxt);
+        int nst = cur.rlen - cur.i0;
+        nst = nst < T ? nst : T;
+        if (full) walk(nst, std::true_type{});
+        else walk(nst, std::false_type{});
+        if (cur.i0 + T >= cur.rlen) {                               // the comb is done: its pieces' d and e, in time order
+            if (j < cur.m) {
+                const size_t at = (size_t)(cur.piece0 + j * cur.pstride) * PP + 16 * wave + c;
+                pd[at] = dsum;
+                pe[at] = D[0];
+            }
+            dsum = 0.0;
+#pragma unroll
+            for (int k = 0; k < NK; k++) D[k] = 0.0;
+        }
+        sync();
+        cur = nxt;
+    }
+    double *out = partial + ((size_t)g * S::NTT + (size_t)wave * NK) * 256;
+#pragma unroll
+    for (int t = 0; t < NK; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[t * 256 + r * 64 + lane] = acc[t][r];
+}
+
+// one split of the shares' matrix-core sums plus one split of the pieces' rank-two terms, in the accumulator layout of
+// v_mfma_f64_16x16x4 (register r of lane l: row l / 16 + 4 r, column l % 16); (row, col) and (col, row) of a diagonal
+// tile evaluate the expression of the ordered pair and agree bit for bit
+template <int NB, int TT>
+__global__ __launch_bounds__(256) void olbm_lane_reduce_kernel(const double *__restrict__ partial, int nshare, int share_split,
+                                                               const double *__restrict__ pe, const double *__restrict__ pd,
+                                                               const int *__restrict__ pcnt, int npieces, int per_split,
+                                                               const double *__restrict__ shift, double *__restrict__ out)
+{
+    using S = LaneShape<NB, TT>;
+    constexpr int PP = S::PP, NTT = S::NTT;
+    const int t = blockIdx.x, e = threadIdx.x, r = e >> 6, l = e & 63;
+    const int qa = t / S::NK, k = t % S::NK, qb = (qa + k) % NB;
+    if (!S::tile_used(qa, k)) return;
+    const int row = 16 * qa + (l >> 4) + 4 * r, col = 16 * qb + (l & 15);
+    const int ia = row < col ? row : col, ib = row < col ? col : row;
+    double s = 0.0;
+    const int g0 = blockIdx.y * share_split, g1 = g0 + share_split < nshare ? g0 + share_split : nshare;
+#pragma unroll 8
+    for (int g = g0; g < g1; g++) s += partial[((size_t)g * NTT + t) * 256 + e];
+    const double sha = shift[ia], shb = shift[ib];
+    const int j0 = blockIdx.y * per_split, j1 = j0 + per_split < npieces ? j0 + per_split : npieces;
+    double cs = 0.0;
+#pragma unroll 8
+    for (int jp = j0; jp < j1; jp++) {
+        const double sa = sha + pe[(size_t)jp * PP + ia], sb = shb + pe[(size_t)jp * PP + ib];
+        const double da = pd[(size_t)jp * PP + ia], db = pd[(size_t)jp * PP + ib];
+        const double tt = fma((double)pcnt[jp], sa, da);
+        cs = fma(tt, sb, cs);
+        cs = fma(sa, db, cs);
+    }
+    out[((size_t)blockIdx.y * NTT + t) * 256 + e] = s + cs;
+}
+
+template <int NB, int TT>
+__global__ __launch_bounds__(256) void olbm_lane_finish_kernel(const double *__restrict__ red, int nsplit, int p, double denom,
+                                                               double *__restrict__ var)
+{
+    using S = LaneShape<NB, TT>;
+    const int t = blockIdx.x, e = threadIdx.x, r = e >> 6, l = e & 63;
+    const int qa = t / S::NK, k = t % S::NK, qb = (qa + k) % NB;
+    if (!S::tile_used(qa, k)) return;
+    double s = 0.0;
+#pragma unroll 16
+    for (int i = 0; i < nsplit; i++) s += red[((size_t)i * S::NTT + t) * 256 + e];
+    const int row = 16 * qa + (l >> 4) + 4 * r, col = 16 * qb + (l & 15);
+    if (row < p && col < p) {
+        const double v = s / denom;                                    // olbm.c:74
+        var[row + (size_t)p * col] = v;
+        var[col + (size_t)p * row] = v;                                // olbm.c:75
+    }
+}
+
+// The plan.  Teeth t = 0 .. Q-1 of len windows (tooth t starts at window t * len) and one of nwin % len; super-blocks of up
+// to four consecutive full teeth are swept together.  A super-block's sweep is cut into UNITS of about R windows (whole
+// multiples of 16), the units are numbered in time order and dealt round-robin: share g walks units g, g + nshare, ...
+// At any moment the workgroups of the chip are then inside the same stretch of nshare * R rows of every tooth row and
+// column: the pages and DRAM rows they touch are shared instead of one private set of 5 * 16 NB streams per wave
+// (len = 1e6 rows, 64 columns: 42.9 ms with contiguous shares -- address translation -- against ... ms dealt this way).
+// Pieces (a unit's run of one tooth) are numbered in time order: super-block, tooth, unit.
+void plan_units(long nwin, long len, long groups, CombPlan &pl)
+{
+    struct SB { long tooth0; int m; long R; };
+    std::vector<SB> sbs;
+    const long Q = nwin / len, rem = nwin % len;
+    for (long t0 = 0; t0 < Q; t0 += 4) sbs.push_back({t0, (int)(Q - t0 < 4 ? Q - t0 : 4), len});
+    if (rem) sbs.push_back({Q, 1, rem});
+    long total = 0;
+    for (auto &sb : sbs) total += sb.R;
+    auto units_of = [&](long rt, long R) { return (R + rt - 1) / rt; };
+    auto count = [&](long rt) {
+        long u = 0;
+        for (auto &sb : sbs) u += units_of(rt, sb.R);
+        return u;
+    };
+    // R: between 6 and 12 rounds of units per share, the candidate that wastes least of the last round (more rounds: more
+    // pieces to chain afterwards -- 24 rounds cost the call of n = 1e8, p = 16 half a millisecond)
+    if (groups < 1) groups = 1;
+    long best_rt = 0;
+    double best_loss = 1e30;
+    for (int k = 6; k <= 12; k++) {
+        long rt = total / (groups * k);
+        rt = (rt + 15) / 16 * 16;
+        if (rt < 256) rt = 256;
+        const long u = count(rt), rounds = (u + groups - 1) / groups;
+        const double loss = (double)(rounds * (u < groups ? u : groups)) / (double)u;
+        if (loss < best_loss - 1e-9) { best_loss = loss; best_rt = rt; }
+        if (rt == 256) break;
+    }
+    const long rt = best_rt;
+    const long nunit = count(rt);
+    const long nshare = nunit < groups ? nunit : groups;
+    std::vector<OlbmComb> units;
+    units.reserve((size_t)nunit);
+    int np = 0;
+    for (auto &sb : sbs) {
+        const long nu = units_of(rt, sb.R);
+        long ru = (sb.R + nu - 1) / nu;                      // equal units inside the super-block
+        ru = (ru + 15) / 16 * 16;
+        int made = 0;
+        for (long r = 0; r < sb.R; r += ru, made++) {
+            OlbmComb c;
+            c.base = sb.tooth0 * len + r;
+            c.m = sb.m;
+            c.rlen = (int)(r + ru <= sb.R ? ru : sb.R - r);
+            c.piece0 = made;                                 // completed below
+            c.pstride = 0;
+            units.push_back(c);
+        }
+        for (size_t i = units.size() - (size_t)made; i < units.size(); i++) {
+            units[i].pstride = made;
+            units[i].piece0 += np;
+        }
+        np += sb.m * made;
+    }
+    pl.npieces = np;
+    pl.pcnt.assign((size_t)np, 0);
+    pl.ptile.assign((size_t)np, 0);
+    for (auto &c : units)
+        for (int k = 0; k < c.m; k++) {
+            const int jp = c.piece0 + k * c.pstride;
+            pl.pcnt[(size_t)jp] = c.rlen;
+            pl.ptile[(size_t)jp] = (c.base % len) == 0;
+        }
+    pl.combs.clear();
+    pl.first.assign(1, 0);
+    pl.steps.clear();
+    pl.max_steps = 0;
+    for (long g = 0; g < nshare; g++) {
+        long st = 0;
+        for (long u = g; u < (long)units.size(); u += nshare) {
+            pl.combs.push_back(units[(size_t)u]);
+            st += (long)units[(size_t)u].m * ((units[(size_t)u].rlen + 15) / 16);
+        }
+        pl.first.push_back((int)pl.combs.size());
+        pl.steps.push_back((int)st);
+        if (st > pl.max_steps) pl.max_steps = st;
+    }
+}
+
+struct LaneState {
+    DevBuf all;
+    double *part = nullptr, *pd = nullptr, *pe = nullptr, *small = nullptr, *red = nullptr;
+    int nshare = 0, np = 0, nchunk = 0, nsplit = 0, per_split = 0, share_split = 0;
+    int *dpcnt = nullptr;
+};
+
+template <int NB, int TT>
+int finish_lane(const double *x, long n, int p, long len, const double *dcentre, double *dmean_out, double *ddelta, double *dvar,
+                DeviceCtx *dc, LaneState &K)
+{
+    using S = LaneShape<NB, TT>;
+    hipStream_t s = dc->stream;
+    const long nwin = n - len + 1;
+    double *csum = K.small, *tsum = csum + (size_t)K.nchunk * S::PP, *s0 = tsum + (size_t)K.nchunk * S::PP, *tail = s0 + S::PP,
+           *shift = tail + S::PP;
+    if (int rc = olbm_first_window_sums(x, n, p, len, dcentre, s0, tail, s)) return rc;
+    if (int rc = olbm_chain_means(tsum, K.nchunk, S::PP, p, s0, tail, dcentre, n, len, dmean_out ? 1 : 0, dmean_out, ddelta, shift, s))
+        return rc;
+    hipLaunchKernelGGL((olbm_lane_reduce_kernel<NB, TT>), dim3((unsigned)S::NTT, (unsigned)K.nsplit), dim3(256), 0, s, K.part, K.nshare,
+                       K.share_split, K.pe, K.pd, K.dpcnt, K.np, K.per_split, shift, K.red);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((olbm_lane_finish_kernel<NB, TT>), dim3((unsigned)S::NTT), dim3(256), 0, s, K.red, K.nsplit, p,
+                       (double)nwin * (double)n * (double)len, dvar);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
+template <int NB, int TT>
+int launch_lane(const double *x, long n, int p, long len, const double *dcentre, double *dmean_out, double *ddelta, double *dvar,
+                DeviceCtx *dc, LaneState &K)
+{
+    using S = LaneShape<NB, TT>;
+    hipStream_t s = dc->stream;
+    const long nwin = n - len + 1;
+    auto kern = olbm_lane_kernel<NB, TT>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
+    int bpc = 1;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, reinterpret_cast<const void *>(kern), 64 * NB, S::lds_bytes));
+    if (bpc < 1) bpc = 1;
+    if (const char *e = getenv("MCMCHIP_OLBM_LANE_GROUPS")) {       // workgroups per CU (experiments)
+        const long v = atol(e);
+        if (v >= 1 && v <= 64) bpc = (int)v;
+    }
+    static const bool dbg = getenv("MCMCHIP_OLBM_LANE_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq[8] = {now()};
+    CombPlan pl;
+    static const bool contiguous = getenv("MCMCHIP_OLBM_LANE_PLAN") && atoi(getenv("MCMCHIP_OLBM_LANE_PLAN")) == 1;
+    if (contiguous) plan_combs(nwin, len, 4, (long)bpc * dc->num_cu, pl);       // one contiguous share per workgroup (experiments)
+    else plan_units(nwin, len, (long)bpc * dc->num_cu, pl);
+    tq[1] = now();
+    const int nshare = (int)pl.steps.size(), np = pl.npieces, nchunk = olbm_chain_chunks(np);
+    int nsplit = (4 * dc->num_cu + S::NTT - 1) / S::NTT;
+    if (nsplit > (np + 15) / 16) nsplit = (np + 15) / 16;
+    if (nsplit < 1) nsplit = 1;
+    const int per_split = (np + nsplit - 1) / nsplit, share_split = (nshare + nsplit - 1) / nsplit;
+
+    const size_t sz_part = (size_t)nshare * S::NTT * 256 * 8, sz_piece = (size_t)np * S::PP * 8,
+                 sz_small = ((size_t)2 * nchunk + 4) * S::PP * 8, sz_red = (size_t)nsplit * S::NTT * 256 * 8;
+    const size_t o_combs = 0, o_first = o_combs + pl.combs.size() * sizeof(OlbmComb), o_pcnt = o_first + pl.first.size() * 4,
+                 o_ptile = o_pcnt + (size_t)np * 4, sz_plan = o_ptile + (size_t)np;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    HIP_TRY(K.all.alloc(up(sz_part) + 2 * up(sz_piece) + up(sz_small) + up(sz_red) + up(sz_plan)));
+    tq[2] = now();
+    char *cursor = K.all.as<char>();
+    auto carve = [&](size_t bytes) { char *r = cursor; cursor += up(bytes); return r; };
+    K.part = (double *)carve(sz_part);
+    K.pd = (double *)carve(sz_piece);
+    K.pe = (double *)carve(sz_piece);
+    K.small = (double *)carve(sz_small);
+    K.red = (double *)carve(sz_red);
+    char *pb = carve(sz_plan);
+    std::vector<char> hplan(sz_plan);
+    memcpy(hplan.data() + o_combs, pl.combs.data(), pl.combs.size() * sizeof(OlbmComb));
+    memcpy(hplan.data() + o_first, pl.first.data(), pl.first.size() * 4);
+    memcpy(hplan.data() + o_pcnt, pl.pcnt.data(), (size_t)np * 4);
+    memcpy(hplan.data() + o_ptile, pl.ptile.data(), (size_t)np);
+    HIP_TRY(hipMemcpyAsync(pb, hplan.data(), sz_plan, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                       // hplan goes out of scope
+    tq[3] = now();
+    K.nshare = nshare;
+    K.np = np;
+    K.nchunk = nchunk;
+    K.nsplit = nsplit;
+    K.per_split = per_split;
+    K.share_split = share_split;
+    K.dpcnt = (int *)(pb + o_pcnt);
+
+    timing_reset("olbm_lane_kernel");
+    timing_begin(s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nshare), dim3(64 * NB), S::lds_bytes, s, x, n, p, len,
+                       (const OlbmComb *)(pb + o_combs), (const int *)(pb + o_first), K.part, K.pd, K.pe);
+    timing_end(s);
+    HIP_TRY(hipGetLastError());
+    if (dbg) { (void)hipStreamSynchronize(s); tq[4] = now(); }
+    double *csum = K.small, *tsum = csum + (size_t)nchunk * S::PP;
+    if (int rc = olbm_chain_pieces(K.pe, (const unsigned char *)(pb + o_ptile), np, S::PP, csum, tsum, s)) return rc;
+    const int rcf = finish_lane<NB, TT>(x, n, p, len, dcentre, dmean_out, ddelta, dvar, dc, K);
+    if (dbg) {
+        (void)hipStreamSynchronize(s);
+        tq[5] = now();
+        fprintf(stderr, "olbm_lane: shares %d units %zu pieces %d | plan %.3f alloc %.3f upload %.3f kernel %.3f post %.3f ms\n", nshare,
+                pl.combs.size(), np, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
+    }
+    return rcf;
+}
+
+}  // namespace
+
+// Host-only check of plan_units (no GPU call; tests/test_host_cpu.py), as mcmchip_olbm_comb_plan_check
+extern "C" int mcmchip_olbm_lane_plan_check(int64_t nwin, int64_t len, int64_t groups, int32_t *npieces, int64_t *min_steps,
+                                            int64_t *max_steps)
+{
+    if (nwin < 1 || len < 1 || groups < 1) return -1;
+    CombPlan pl;
+    plan_units((long)nwin, (long)len, (long)groups, pl);
+    long lo = 0, hi = 0;
+    const int bad = olbm_plan_violations(pl, (long)nwin, (long)len, 4, npieces, &lo, &hi);
+    if (min_steps) *min_steps = lo;
+    if (max_steps) *max_steps = hi;
+    return bad;
+}
+
+bool olbm_lane_applies(long n, int p, long len)
+{
+    static const char *env = getenv("MCMCHIP_OLBM_LANE");
+    if (env && env[0] == '0') return false;
+    // Measured at n = 1e8, len = 1e4 (ms per call, this kernel / what served before): p = 5: 2.7 / 3.0 (olbm_small), p = 8:
+    // 2.9 / 5.9, p = 9: 2.9 / 14.6 (olbm_mfma_kernel), p = 16: 3.4 / 14.7, p = 32: 6.6 / 16.0, p = 64: 16.5 / 23.0; p <= 4 stays
+    // with olbm_small (p = 4: 2.65 / 2.3), and so does a short series of few columns (the plan and the chain cost 0.5 ms).
+    // MCMCHIP_OLBM_LANE=<min len> lowers the window threshold and takes every p <= 64 (tests/fuzz_olbm_lane.py).
+    long min_len = 256;
+    int min_p = 5;
+    long min_n_few = 2000000;
+    if (env && atol(env) > 1) { min_len = atol(env); min_p = 1; min_n_few = 0; }
+    const long nwin = n - len + 1;
+    if (p <= 8 && n < min_n_few) return false;
+    return p >= min_p && p <= 64 && len >= min_len && nwin >= 4 * len;
+}
+
+int run_olbm_lane(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc)
+{
+    hipStream_t s = dc->stream;
+    DevBuf vecs;                                              // var | mean | centre | delta
+    HIP_TRY(vecs.alloc(((size_t)p * p + 3 * (size_t)p) * 8));
+    double *dvar = vecs.as<double>(), *dmean = dvar + (size_t)p * p, *dcentre = dmean + p, *ddelta = dcentre + p;
+    const bool one_pass = !nocalc && n >= OL_ONEPASS_MIN_N;   // as in olbm_comb.hip
+    if (nocalc) HIP_TRY(hipMemcpyAsync(dmean, mean, (size_t)p * 8, hipMemcpyHostToDevice, s));
+    else if (one_pass) { if (int rc = olbm_pilot_centre(x, n, p, dcentre, s)) return rc; }
+    else if (int rc = olbm_exact_means(x, n, p, dmean, s)) return rc;
+    LaneState K;
+    const double *centre = one_pass ? dcentre : dmean;
+    double *mean_out = one_pass ? dmean : nullptr;
+    const int nb = (p + 15) / 16;
+    static const int tt = getenv("MCMCHIP_OLBM_LANE_T") ? atoi(getenv("MCMCHIP_OLBM_LANE_T")) : 32;
+    auto walk = [&](bool first_time, const double *cen, double *mo, double *dl) {
+#define OL_CASE(NBV)                                                                                         \
+    if (nb == NBV && tt == 64)                                                                               \
+        return first_time ? launch_lane<NBV, 64>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
+                          : finish_lane<NBV, 64>(x, n, p, len, cen, mo, dl, dvar, dc, K);                    \
+    if (nb == NBV)                                                                                           \
+        return first_time ? launch_lane<NBV, 32>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
+                          : finish_lane<NBV, 32>(x, n, p, len, cen, mo, dl, dvar, dc, K);
+        OL_CASE(1) OL_CASE(2) OL_CASE(3) OL_CASE(4)
+#undef OL_CASE
+        return set_error(MCMCHIP_EINVAL, "olbm_lane: p > 64");
+    };
+    if (int rc = walk(true, centre, mean_out, ddelta)) return rc;
+    HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
+    if (!nocalc) HIP_TRY(hipMemcpyAsync(mean, dmean, (size_t)p * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (one_pass) {
+        // the sampled centre enters only through s0 - len * delta; beyond three digits lost there the finish (not the walk)
+        // is repeated about the exact mean
+        std::vector<double> hd((size_t)p);
+        HIP_TRY(hipMemcpy(hd.data(), ddelta, (size_t)p * 8, hipMemcpyDeviceToHost));
+        bool redo = false;
+        for (int c = 0; c < p; c++) {
+            const double main_term = var[c + (size_t)p * c] * (double)n;
+            const double corr = (double)len * hd[c] * hd[c];
+            if (!(corr <= OL_ONEPASS_MAX_LOSS * main_term) && !(fabs(hd[c]) <= 1e-14 * fabs(mean[c]))) redo = true;
+        }
+        if (redo) {
+            if (int rc = walk(false, dmean, nullptr, nullptr)) return rc;
+            HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
+    return MCMCHIP_OK;
+}

@@ -1,5 +1,6 @@
 // olbm_shape.h -- tile / LDS geometry shared by the two matrix-core olbm kernels (diag.hip, olbm_comb.hip)
 #pragma once
+#include <vector>
 #define OM_SLAB 16
 #define OM_NW 8
 #define OL_ONEPASS_MIN_N (1L << 20)      // shorter series: the means come from colsum_kernel first, as in olbm.c:38-43
@@ -50,6 +51,33 @@ int run_olbm_comb(const double *x, long n, int p, long len, double *mean, double
 // olbm_comb.hip: s0[c] = sum over the first window of (x - centre), tail[c] = the same over the rows after the last window
 // that starts at a multiple of len
 int olbm_first_window_sums(const double *x, long n, int p, long len, const double *dcentre, double *s0, double *tail, hipStream_t s);
+// olbm_comb.hip: the plan of a comb walk (shared with olbm_lane.hip)
+struct OlbmComb {
+    long base;          // first window of tooth 0
+    int m;              // teeth, len windows apart
+    int rlen;           // windows per tooth in this comb (the sweep)
+    int piece0;         // piece of tooth k: piece0 + k * pstride (pieces are numbered in time order)
+    int pstride;
+};
+struct CombPlan {
+    std::vector<OlbmComb> combs;
+    std::vector<int> first, steps, pcnt;
+    std::vector<unsigned char> ptile;
+    int npieces = 0;
+    long max_steps = 0;
+};
+void plan_combs(long nwin, long len, int teeth, long groups, CombPlan &pl);
+// host-only check of a plan (every window once, pieces in time order and contiguous, step counts consistent): violations
+int olbm_plan_violations(const CombPlan &pl, long nwin, long len, int teeth, int *npieces, long *min_steps, long *max_steps);
+// chain of the pieces: e_j -> E_j in place, sums of the E_j of the pieces that start a tooth per chunk of pieces (tsum);
+// then the exact means (want_mean) and shift = s0 - len * delta
+int olbm_chain_chunks(int npieces);
+int olbm_chain_pieces(double *pe, const unsigned char *ptile, int npieces, int PP, double *csum, double *tsum, hipStream_t s);
+int olbm_chain_means(const double *tsum, int nchunk, int PP, int p, const double *s0, const double *tail, const double *centre,
+                     long n, long len, int want_mean, double *mean, double *delta, double *shift, hipStream_t s);
+// olbm_lane.hip: 9 <= p <= 64 columns, long windows: a wave walks four teeth, one lane per (tooth, column)
+bool olbm_lane_applies(long n, int p, long len);
+int run_olbm_lane(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc);
 // olbm_small.hip: p <= 8 on the vector units
 bool olbm_small_applies(long n, int p, long len);
 int run_olbm_small(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc);

@@ -47,7 +47,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     st = np.sqrt(np.outer(np.diag(true), np.diag(true))) + 1e-300
     t_dev, t_orc = np.max(np.abs(got_d[:k, :k] - true) / st), np.max(np.abs(ref[:k, :k] - true) / st)
     sym = np.array_equal(got, got.T) and np.array_equal(got_d, got_d.T)
-    flag = "" if (err_a < 1e-10 and err_b < 1e-10 and sym) else "  <<<<<<"
+    flag = "" if (max(err_a, err_b) < 1e-10 + 3 * t_orc and sym) else "  <<<<<<"   # olbm.c itself is t_orc away from the 80-bit value
     bad += bool(flag)
     print("n=%d p=%d len=%d teeth=%s  means given %.2e  computed %.2e  vs 80-bit: device %.1e oracle %.1e  sym %s%s" % (n, p, blen, os.environ["MCMCHIP_OLBM_TEETH"], err_a, err_b, t_dev, t_orc, sym, flag), flush=True)
 print("bad", bad)

@@ -863,8 +863,62 @@ def test_olbm_comb_route_vs_oracle(api, oracle_mod, n, p, blen):
     v3, m3 = api.olbm_device(xd, blen)
     assert np.array_equal(v3, got2)
     assert np.all(np.abs(m3[:k] - exact) <= 1e-14 * np.abs(exact))
-    # up to 8 columns: the streaming kernel on the vector units (olbm_small.hip); up to 64: the two-stream matrix-core kernel
-    assert api.last_kernel_time()[0] == ("olbm_comb_kernel" if p > 64 else ("olbm_mfma_kernel" if p > 8 else "olbm_small_kernel"))
+    assert api.last_kernel_time()[0] == _olbm_route(n, p, blen)
+
+
+def _olbm_route(n, p, blen):
+    """Which kernel diag.hip::run_olbm hands a shape to (olbm_small_applies / olbm_lane_applies / olbm_comb_applies)."""
+    nwin = n - blen + 1
+    lane = 5 <= p <= 64 and blen >= 256 and nwin >= 4 * blen and (p > 8 or n >= 2_000_000)
+    if lane:
+        return "olbm_lane_kernel"        # a lane per (tooth, column), no scan (olbm_lane.hip)
+    if p <= 8:
+        return "olbm_small_kernel"       # the streaming kernel on the vector units (olbm_small.hip)
+    if p > 64 and p <= 256 and blen >= 1024 and nwin >= 2 * blen:
+        return "olbm_comb_kernel"        # x read once, window sums by a scan, 16 consecutive windows per instruction
+    return "olbm_mfma_kernel"            # the two-stream matrix-core kernel
+
+
+@pytest.mark.parametrize("n,p,blen", [(300_000, 9, 256), (200_000, 16, 1000), (120_000, 31, 5000), (90_000, 48, 3001),
+                                       (2_100_000, 6, 4096), (64_000, 64, 12_800), (70_001, 33, 777), (2_000_003, 5, 400_000)])
+def test_olbm_lane_route_vs_oracle(api, oracle_mod, n, p, blen):
+    """5 .. 64 columns and windows of >= 256 rows take olbm_lane.hip: a wave walks four teeth one window length apart with
+    one lane per (tooth, column), window sums are running sums in registers (no scan), five rows feed four teeth, units of
+    the sweep are dealt round-robin to the workgroups, pieces chained and rank-two terms added afterwards, exact means out
+    of the chain.  Against the oracle at 1e-10 (1e-9 where olbm.c's own arithmetic is good for no more: windows beyond
+    10 000 rows or a quarter of the series) with the means supplied and computed by the call, against an 80-bit
+    evaluation of the definition at 1e-12; every block count (16, 32, 48, 64 padded columns), a remainder tooth, a last
+    super-block of fewer than four teeth, ragged units."""
+    import math
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(n % 1000 + p)
+    x = np.empty((n, p))
+    for c in range(p):
+        x[:, c] = lfilter([1.0], [1.0, -(0.1 + 0.85 * c / p)], rng.standard_normal(n)) + (3.0 + 50.0 * (c % 3))
+    x[:, 1] += np.linspace(-5.0, 5.0, n)
+    ref, refmean = oracle_mod.olbm(x, blen)
+    sc = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    tol = 1e-10 if blen <= 10_000 and 4 * blen <= n else 1e-9
+    got = api.olbm(x, blen)                          # means supplied
+    assert api.last_kernel_time()[0] == "olbm_lane_kernel" == _olbm_route(n, p, blen)
+    assert np.all(np.abs(got - ref) <= tol * sc)
+    assert np.array_equal(got, got.T)
+    got2 = api.olbm(x, blen, demean=False)           # means computed by the call
+    assert np.all(np.abs(got2 - ref) <= tol * sc)
+    assert np.array_equal(got2, got2.T)
+    k = min(p, 4)
+    exact = np.array([math.fsum(x[:, c]) / n for c in range(k)])
+    xl = x[:, :k].astype(np.longdouble) - exact.astype(np.longdouble)
+    cs = np.vstack([np.zeros((1, k), dtype=np.longdouble), np.cumsum(xl, axis=0)])
+    V = cs[blen:] - cs[:-blen]
+    true = np.asarray((V.T @ V) / (np.longdouble(n - blen + 1) * n * blen), dtype=np.float64)
+    st = np.sqrt(np.outer(np.diag(true), np.diag(true)))
+    assert np.all(np.abs(got2[:k, :k] - true) <= 1e-12 * st)
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x.T)).to("cuda:0")
+    v3, m3 = api.olbm_device(xd, blen)
+    assert np.array_equal(v3, got2)
+    assert np.all(np.abs(m3[:k] - exact) <= 1e-14 * np.abs(exact))
 
 
 @pytest.mark.parametrize("n,p,blen", [(1_200_000, 5, 1000), (1_048_576, 70, 64), (1_100_003, 3, 1), (1_300_000, 130, 4097),

@@ -299,3 +299,29 @@ def test_olbm_comb_plan_covers_every_window_once():
     assert f(99_990_257, 10_000, 5, 256, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0
     # C5: the busiest of the 256 workgroups is within one comb step (5 slabs) of the mean
     assert hi.value <= -(-99_990_257 // (16 * 256)) + 5 and 10_000 <= npieces.value <= 12_000
+
+
+def test_olbm_lane_plan_covers_every_window_once():
+    """The plan of olbm_lane.hip (super-blocks of four teeth, units of the sweep dealt round-robin to the workgroups): every
+    window in exactly one piece, pieces in time order without gaps, step counts consistent; the busiest workgroup of the
+    n = 1e8, len = 1e4 shape within 10 % of the mean.  No GPU call."""
+    import ctypes as C
+    from mcmc_amd import api
+    f = api.load_library().mcmchip_olbm_lane_plan_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(4)
+    npieces, lo, hi = C.c_int32(), C.c_int64(), C.c_int64()
+    cases = [(99_990_001, 10_000, 2304), (17, 16, 256), (1, 1, 1), (33, 16, 3), (4097, 1024, 512), (2_000_001, 1_000_000, 256),
+             (1_600_004, 400_000, 2304), (51_201, 12_800, 512)]
+    for _ in range(300):
+        ln = int(rng.choice([1, 2, 15, 16, 17, 31, 100, 256, 1024, 1027, 4096, 20_000]))
+        nwin = int(rng.integers(1, 60)) * ln + int(rng.integers(0, ln))
+        cases.append((max(nwin, 1), ln, int(rng.choice([1, 2, 7, 256, 1024, 2304]))))
+    for nwin, ln, groups in cases:
+        assert f(nwin, ln, groups, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0, (nwin, ln, groups)
+        assert npieces.value >= -(-nwin // ln)
+    for groups in (512, 768, 1024, 2304):
+        assert f(99_990_001, 10_000, groups, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0
+        mean_steps = 99_990_001 / 16 / groups
+        assert hi.value <= 1.10 * mean_steps + 8, (groups, hi.value, mean_steps)
