@@ -40,9 +40,12 @@ template <int NB, int TT> struct LaneShape {
     static constexpr int KPR = 16 / SEG;                            // load instructions per tooth row (a wave loads 16 columns)
     static constexpr int H = NB / 2;
     static constexpr int NK = H + 1;                                // tiles of wave w: (w, (w + k) % NB), k = 0 .. H
-    static constexpr int NTT = NB * NK;                             // tile slots (the k = H slots of waves >= NB / 2 stay empty for even NB)
+    static constexpr int NTT = NB * NK;                             // tile slots
     static constexpr size_t lds_bytes = (size_t)NB * 4 * 16 * TP * 8;
-    __host__ __device__ static constexpr bool tile_used(int w, int k) { return NB == 1 || k < H || NB % 2 == 1 || w < NB / 2; }
+    // even NB: the pair (w, w + H) would be met twice by the circulant; waves w and w + H share it instead -- w takes the
+    // first two of every four steps as tile (w, w + H), w + H the other two as its transpose, and the finish adds them
+    static constexpr bool SHARED_H = NB > 1 && NB % 2 == 0;
+    __host__ __device__ static constexpr bool is_partner(int w, int k) { return SHARED_H && k == H && w >= NB / 2; }
 };
 
 // A workgroup = one share of the plan; wave w loads the 16 columns of block w (five rows of T steps for four teeth),
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__rest
     const int g = blockIdx.x;
     const int j = lane >> 4, c = lane & 15;                         // the walk: tooth, column inside a block of 16
     const int li = lane % T, lseg = lane / T;                       // the loads: step inside the chunk, column run
-    const bool full = S::tile_used(wave, NK - 1);                   // does this wave own a k = H tile
+    const bool upper = S::SHARED_H && wave >= NB / 2;               // which half of the steps of the shared k = H tile
 
     om_double4 acc[NK];
 #pragma unroll
@@ -143,16 +146,17 @@ __global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__rest
     const double *Wr[NK];
 #pragma unroll
     for (int k = 0; k < NK; k++) Wr[k] = W + (size_t)((wave + k) % NB) * 64 * TP + (j * 16 + c) * TP;
-    auto step = [&](const double (&d)[NK], auto fullc) {
+    auto step = [&](const double (&d)[NK], auto with_h) {
 #pragma unroll
         for (int k = 0; k < NK; k++)
-            if (k < NK - 1 || NK == 1 || decltype(fullc)::value)
+            if (k < NK - 1 || NK == 1 || decltype(with_h)::value)
                 acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], D[k], acc[k], 0, 0, 0);
         dsum += D[0];
 #pragma unroll
         for (int k = 0; k < NK; k++) D[k] += d[k];
     };
-    auto walk = [&](int nst, auto fullc) {
+    auto walk = [&](int nst, auto upperc) {
+        constexpr bool up = decltype(upperc)::value;
         int i = 0;
         for (; i + 4 <= nst; i += 4) {
             double d[4][NK];
@@ -160,14 +164,16 @@ __global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__rest
             for (int u = 0; u < 4; u++)
 #pragma unroll
                 for (int k = 0; k < NK; k++) d[u][k] = Wr[k][i + u];
-#pragma unroll
-            for (int u = 0; u < 4; u++) step(d[u], fullc);
+            step(d[0], std::bool_constant<!S::SHARED_H || !up>{});
+            step(d[1], std::bool_constant<!S::SHARED_H || !up>{});
+            step(d[2], std::bool_constant<!S::SHARED_H || up>{});
+            step(d[3], std::bool_constant<!S::SHARED_H || up>{});
         }
-        for (; i < nst; i++) {
+        for (; i < nst; i++) {                                      // the ragged end of a unit: the lower wave's
             double d[NK];
 #pragma unroll
             for (int k = 0; k < NK; k++) d[k] = Wr[k][i];
-            step(d, fullc);
+            step(d, std::bool_constant<!S::SHARED_H || !up>{});
         }
     };
     while (cur.ci < ci_end) {
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__rest
         issue(nxt);
         int nst = cur.rlen - cur.i0;
         nst = nst < T ? nst : T;
-        if (full) walk(nst, std::true_type{});
+        if (upper) walk(nst, std::true_type{});
         else walk(nst, std::false_type{});
         if (cur.i0 + T >= cur.rlen) {                               // the comb is done: its pieces' d and e, in time order
             if (j < cur.m) {
@@ -213,7 +219,6 @@ __global__ __launch_bounds__(256) void olbm_lane_reduce_kernel(const double *__r
     constexpr int PP = S::PP, NTT = S::NTT;
     const int t = blockIdx.x, e = threadIdx.x, r = e >> 6, l = e & 63;
     const int qa = t / S::NK, k = t % S::NK, qb = (qa + k) % NB;
-    if (!S::tile_used(qa, k)) return;
     const int row = 16 * qa + (l >> 4) + 4 * r, col = 16 * qb + (l & 15);
     const int ia = row < col ? row : col, ib = row < col ? col : row;
     double s = 0.0;
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(256) void olbm_lane_reduce_kernel(const double *__r
 #pragma unroll 8
     for (int g = g0; g < g1; g++) s += partial[((size_t)g * NTT + t) * 256 + e];
     const double sha = shift[ia], shb = shift[ib];
-    const int j0 = blockIdx.y * per_split, j1 = j0 + per_split < npieces ? j0 + per_split : npieces;
-    double cs = 0.0;
+    const int j0 = blockIdx.y * per_split, j1 = S::is_partner(qa, k) ? 0 : (j0 + per_split < npieces ? j0 + per_split : npieces);
+    double cs = 0.0;                                                // a partner slot holds matrix-core sums only
 #pragma unroll 8
     for (int jp = j0; jp < j1; jp++) {
         const double sa = sha + pe[(size_t)jp * PP + ia], sb = shb + pe[(size_t)jp * PP + ib];
@@ -241,10 +246,18 @@ __global__ __launch_bounds__(256) void olbm_lane_finish_kernel(const double *__r
     using S = LaneShape<NB, TT>;
     const int t = blockIdx.x, e = threadIdx.x, r = e >> 6, l = e & 63;
     const int qa = t / S::NK, k = t % S::NK, qb = (qa + k) % NB;
-    if (!S::tile_used(qa, k)) return;
+    if (S::is_partner(qa, k)) return;
     double s = 0.0;
 #pragma unroll 16
     for (int i = 0; i < nsplit; i++) s += red[((size_t)i * S::NTT + t) * 256 + e];
+    if (S::SHARED_H && k == S::H) {                                    // the other half of the steps, transposed, in wave qb's slot
+        const int ri = (l >> 4) + 4 * r, ci = l & 15;
+        const int tp = qb * S::NK + S::H, ep = (ci >> 2) * 64 + (ci & 3) * 16 + ri;
+        double sp = 0.0;
+#pragma unroll 16
+        for (int i = 0; i < nsplit; i++) sp += red[((size_t)i * S::NTT + tp) * 256 + ep];
+        s += sp;
+    }
     const int row = 16 * qa + (l >> 4) + 4 * r, col = 16 * qb + (l & 15);
     if (row < p && col < p) {
         const double v = s / denom;                                    // olbm.c:74
@@ -495,15 +508,18 @@ int run_olbm_lane(const double *x, long n, int p, long len, double *mean, double
     const double *centre = one_pass ? dcentre : dmean;
     double *mean_out = one_pass ? dmean : nullptr;
     const int nb = (p + 15) / 16;
-    static const int tt = getenv("MCMCHIP_OLBM_LANE_T") ? atoi(getenv("MCMCHIP_OLBM_LANE_T")) : 32;
+    static const int tt = getenv("MCMCHIP_OLBM_LANE_T") ? atoi(getenv("MCMCHIP_OLBM_LANE_T")) : 16;
     auto walk = [&](bool first_time, const double *cen, double *mo, double *dl) {
 #define OL_CASE(NBV)                                                                                         \
     if (nb == NBV && tt == 64)                                                                               \
         return first_time ? launch_lane<NBV, 64>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
                           : finish_lane<NBV, 64>(x, n, p, len, cen, mo, dl, dvar, dc, K);                    \
-    if (nb == NBV)                                                                                           \
+    if (nb == NBV && tt == 32)                                                                               \
         return first_time ? launch_lane<NBV, 32>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
-                          : finish_lane<NBV, 32>(x, n, p, len, cen, mo, dl, dvar, dc, K);
+                          : finish_lane<NBV, 32>(x, n, p, len, cen, mo, dl, dvar, dc, K);                    \
+    if (nb == NBV)                                                                                           \
+        return first_time ? launch_lane<NBV, 16>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
+                          : finish_lane<NBV, 16>(x, n, p, len, cen, mo, dl, dvar, dc, K);
         OL_CASE(1) OL_CASE(2) OL_CASE(3) OL_CASE(4)
 #undef OL_CASE
         return set_error(MCMCHIP_EINVAL, "olbm_lane: p > 64");
