@@ -1,5 +1,5 @@
-// olbm_lane.hip -- olbm() (reference olbm.c:22-78) for 9 .. 64 columns and long windows: a wave walks FOUR TEETH of a comb
-// with one lane per (tooth, column), and nothing is scanned.
+// olbm_lane.hip -- olbm() (reference olbm.c:22-78) for 5 .. 192 columns and windows of >= 256 rows: a wave walks FOUR TEETH of
+// a comb with one lane per (tooth, column), and nothing is scanned.
 //
 // v_mfma_f64_16x16x4_f64 takes a 16 x 4 operand: lane l supplies element (column l % 16, k = l / 16).  olbm_mfma_kernel
 // and olbm_comb_kernel fill k with four CONSECUTIVE windows, which is why they need a producer: window sums of 16
@@ -16,10 +16,16 @@
 // afterwards from one direct sum per column (olbm_comb.hip's chain kernels, shared); the exact means (olbm.c:38-43) come
 // out of the chain too.
 //
-// Memory: a wave loads whole 64 .. 256-byte runs of a column (coalesced, [column][time]), keeps the NEXT chunk in
-// registers while it works on the current one (80 VGPRs in flight per lane: 20 KB per wave, 160 KB per CU), takes the
-// differences in that layout, and turns them to [tooth][column] through a wave-private piece of LDS (odd pitch, no
-// bank conflicts, no workgroup barrier anywhere in the kernel).
+// Columns come in blocks of 16 (NB = 1 .. 12); a workgroup has one wave per block.  Wave w loads its block -- whole 128-byte
+// runs of a column, coalesced, [column][time] -- keeps the NEXT chunk in registers while the current one is worked on
+// (40 VGPRs in flight per lane: 10 KB per wave), takes the differences in that layout and turns them to [tooth][column]
+// through LDS (odd pitch, no bank conflicts), where the blocks meet: wave w accumulates the tiles (w, w), (w, w+1), ..,
+// (w, w + NB/2) of the circulant, every unordered pair of blocks once (for even NB the farthest pair is shared between
+// waves w and w + NB/2, half of the steps each).  Two workgroup barriers per chunk; NB = 1 needs none.
+//
+// The plan deals units of the sweep round-robin to the workgroups (plan_units below): the chip then works inside one
+// stretch of every row and column at a time, which is what the DRAM pages and the address translation want -- 6.5 TB/s
+// of HBM traffic at p = 16 by the counters, and no slowdown for windows of 1e5 .. 1e6 rows (contiguous shares: 2 .. 2.6 x).
 #include "kernels.h"
 #include "olbm_shape.h"
 #include <math.h>
@@ -32,6 +38,10 @@
 
 namespace {
 
+// beyond 12 blocks of 16 columns a workgroup of one wave per block leaves a wave 128 registers: the accumulators of 7+ tiles,
+// the chunk in flight and the running sums do not fit (spills); 193 .. 256 columns stay with olbm_comb.hip
+#define OL_LANE_MAX_P 192
+
 template <int NB, int TT> struct LaneShape {
     static constexpr int PP = 16 * NB;                              // padded columns
     static constexpr int T = TT;                                    // steps per chunk
@@ -43,7 +53,8 @@ template <int NB, int TT> struct LaneShape {
     static constexpr int NTT = NB * NK;                             // tile slots
     static constexpr size_t lds_bytes = (size_t)NB * 4 * 16 * TP * 8;
     // even NB: the pair (w, w + H) would be met twice by the circulant; waves w and w + H share it instead -- w takes the
-    // first two of every four steps as tile (w, w + H), w + H the other two as its transpose, and the finish adds them
+    // first half of every group of four (two) steps as tile (w, w + H), w + H the other half as its transpose, and the
+    // finish adds them
     static constexpr bool SHARED_H = NB > 1 && NB % 2 == 0;
     __host__ __device__ static constexpr bool is_partner(int w, int k) { return SHARED_H && k == H && w >= NB / 2; }
 };
@@ -146,34 +157,33 @@ __global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__rest
     const double *Wr[NK];
 #pragma unroll
     for (int k = 0; k < NK; k++) Wr[k] = W + (size_t)((wave + k) % NB) * 64 * TP + (j * 16 + c) * TP;
-    auto step = [&](const double (&d)[NK], auto with_h) {
+    auto step = [&](const double (&d)[NK], bool with_h) {          // with_h: wave-uniform
 #pragma unroll
-        for (int k = 0; k < NK; k++)
-            if (k < NK - 1 || NK == 1 || decltype(with_h)::value)
-                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], D[k], acc[k], 0, 0, 0);
+        for (int k = 0; k < NK - 1; k++) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], D[k], acc[k], 0, 0, 0);
+        if (!S::SHARED_H || with_h) acc[NK - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], D[NK - 1], acc[NK - 1], 0, 0, 0);
         dsum += D[0];
 #pragma unroll
         for (int k = 0; k < NK; k++) D[k] += d[k];
     };
-    auto walk = [&](int nst, auto upperc) {
-        constexpr bool up = decltype(upperc)::value;
+    auto walk = [&](int nst) {
+        constexpr int G = NB >= 9 ? 2 : 4;                          // steps whose differences are read ahead (registers: G NK doubles)
         int i = 0;
-        for (; i + 4 <= nst; i += 4) {
-            double d[4][NK];
+        for (; i + G <= nst; i += G) {
+            double d[G][NK];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < G; u++)
 #pragma unroll
                 for (int k = 0; k < NK; k++) d[u][k] = Wr[k][i + u];
-            step(d[0], std::bool_constant<!S::SHARED_H || !up>{});
-            step(d[1], std::bool_constant<!S::SHARED_H || !up>{});
-            step(d[2], std::bool_constant<!S::SHARED_H || up>{});
-            step(d[3], std::bool_constant<!S::SHARED_H || up>{});
+#pragma unroll
+            for (int u = 0; u < G / 2; u++) step(d[u], !upper);
+#pragma unroll
+            for (int u = G / 2; u < G; u++) step(d[u], upper);
         }
         for (; i < nst; i++) {                                      // the ragged end of a unit: the lower wave's
             double d[NK];
 #pragma unroll
             for (int k = 0; k < NK; k++) d[k] = Wr[k][i];
-            step(d, std::bool_constant<!S::SHARED_H || !up>{});
+            step(d, !upper);
         }
     };
     while (cur.ci < ci_end) {
@@ -184,8 +194,7 @@ __global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__rest
         issue(nxt);
         int nst = cur.rlen - cur.i0;
         nst = nst < T ? nst : T;
-        if (upper) walk(nst, std::true_type{});
-        else walk(nst, std::false_type{});
+        walk(nst);
         if (cur.i0 + T >= cur.rlen) {                               // the comb is done: its pieces' d and e, in time order
             if (j < cur.m) {
                 const size_t at = (size_t)(cur.piece0 + j * cur.pstride) * PP + 16 * wave + c;
@@ -271,7 +280,8 @@ __global__ __launch_bounds__(256) void olbm_lane_finish_kernel(const double *__r
 // multiples of 16), the units are numbered in time order and dealt round-robin: share g walks units g, g + nshare, ...
 // At any moment the workgroups of the chip are then inside the same stretch of nshare * R rows of every tooth row and
 // column: the pages and DRAM rows they touch are shared instead of one private set of 5 * 16 NB streams per wave
-// (len = 1e6 rows, 64 columns: 42.9 ms with contiguous shares -- address translation -- against ... ms dealt this way).
+// (n = 1e8, len = 1e6 rows, 64 columns: 43 ms with contiguous shares -- address translation -- against 17 ms dealt this way;
+// len = 1e4, 16 columns: 3.7 against 2.6 ms).
 // Pieces (a unit's run of one tooth) are numbered in time order: super-block, tooth, unit.
 void plan_units(long nwin, long len, long groups, CombPlan &pl)
 {
@@ -481,17 +491,19 @@ bool olbm_lane_applies(long n, int p, long len)
 {
     static const char *env = getenv("MCMCHIP_OLBM_LANE");
     if (env && env[0] == '0') return false;
-    // Measured at n = 1e8, len = 1e4 (ms per call, this kernel / what served before): p = 5: 2.7 / 3.0 (olbm_small), p = 8:
-    // 2.9 / 5.9, p = 9: 2.9 / 14.6 (olbm_mfma_kernel), p = 16: 3.4 / 14.7, p = 32: 6.6 / 16.0, p = 64: 16.5 / 23.0; p <= 4 stays
-    // with olbm_small (p = 4: 2.65 / 2.3), and so does a short series of few columns (the plan and the chain cost 0.5 ms).
-    // MCMCHIP_OLBM_LANE=<min len> lowers the window threshold and takes every p <= 64 (tests/fuzz_olbm_lane.py).
+    // Measured at n = 1e8, len = 1e4 (ms per call, this kernel / what served before): p = 5: 2.3 / 3.1 (olbm_small), p = 8:
+    // 2.4 / 6.0, p = 9: 2.5 / 14.5 (olbm_mfma_kernel), p = 16: 3.1 / 14.6, p = 32: 6.2 / 15.9, p = 64: 15.7 / 22.3, p = 65: 23.9 / 45.0
+    // (olbm_comb_kernel), p = 128: 43.7 / 46.5, p = 129: 65.4 / 113.1, p = 192: 81.2 / 113.6; p <= 4 stays with olbm_small
+    // (p = 4: 2.65 / 2.3), and so does a short series of few columns (the plan and the chain cost 0.5 ms).
+    // MCMCHIP_OLBM_LANE=<min len> lowers the window threshold and takes every p <= 192 (tests/fuzz_olbm_lane.py).
     long min_len = 256;
     int min_p = 5;
     long min_n_few = 2000000;
     if (env && atol(env) > 1) { min_len = atol(env); min_p = 1; min_n_few = 0; }
     const long nwin = n - len + 1;
     if (p <= 8 && n < min_n_few) return false;
-    return p >= min_p && p <= 64 && len >= min_len && nwin >= 4 * len;
+    static const int max_p = getenv("MCMCHIP_OLBM_LANE_MAXP") ? atoi(getenv("MCMCHIP_OLBM_LANE_MAXP")) : OL_LANE_MAX_P;
+    return p >= min_p && p <= max_p && len >= min_len && nwin >= 4 * len;
 }
 
 int run_olbm_lane(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc)
@@ -510,19 +522,18 @@ int run_olbm_lane(const double *x, long n, int p, long len, double *mean, double
     const int nb = (p + 15) / 16;
     static const int tt = getenv("MCMCHIP_OLBM_LANE_T") ? atoi(getenv("MCMCHIP_OLBM_LANE_T")) : 16;
     auto walk = [&](bool first_time, const double *cen, double *mo, double *dl) {
-#define OL_CASE(NBV)                                                                                         \
-    if (nb == NBV && tt == 64)                                                                               \
-        return first_time ? launch_lane<NBV, 64>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
-                          : finish_lane<NBV, 64>(x, n, p, len, cen, mo, dl, dvar, dc, K);                    \
-    if (nb == NBV && tt == 32)                                                                               \
-        return first_time ? launch_lane<NBV, 32>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
-                          : finish_lane<NBV, 32>(x, n, p, len, cen, mo, dl, dvar, dc, K);                    \
-    if (nb == NBV)                                                                                           \
-        return first_time ? launch_lane<NBV, 16>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
-                          : finish_lane<NBV, 16>(x, n, p, len, cen, mo, dl, dvar, dc, K);
+#define OL_CASE_T(NBV, TV)                                                                                   \
+    if (nb == NBV && (tt == TV || TV == 16))                                                                 \
+        return first_time ? launch_lane<NBV, TV>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \
+                          : finish_lane<NBV, TV>(x, n, p, len, cen, mo, dl, dvar, dc, K);
+#define OL_CASE(NBV) OL_CASE_T(NBV, 64) OL_CASE_T(NBV, 32) OL_CASE_T(NBV, 16)
         OL_CASE(1) OL_CASE(2) OL_CASE(3) OL_CASE(4)
+#define OL_CASE16(NBV) OL_CASE_T(NBV, 16)
+        OL_CASE16(5) OL_CASE16(6) OL_CASE16(7) OL_CASE16(8) OL_CASE16(9) OL_CASE16(10) OL_CASE16(11) OL_CASE16(12)
+#undef OL_CASE16
+#undef OL_CASE_T
 #undef OL_CASE
-        return set_error(MCMCHIP_EINVAL, "olbm_lane: p > 64");
+        return set_error(MCMCHIP_EINVAL, "olbm_lane: p > 192");
     };
     if (int rc = walk(true, centre, mean_out, ddelta)) return rc;
     HIP_TRY(hipMemcpyAsync(var, dvar, (size_t)p * p * 8, hipMemcpyDeviceToHost, s));

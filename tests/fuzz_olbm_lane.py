@@ -1,6 +1,6 @@
-"""One-off fuzz of the lane-per-(tooth, column) olbm kernel (olbm_lane.hip, p <= 64, long windows) against the oracle and
+"""One-off fuzz of the lane-per-(tooth, column) olbm kernel (olbm_lane.hip, p <= 192, long windows) against the oracle and
 an 80-bit evaluation (not collected by pytest).  usage (GPU box): MCMCHIP_OLBM_LANE=8 python tests/fuzz_olbm_lane.py
-[nrounds] [seed]   (the environment value lowers the window threshold to 8 rows and takes every p <= 64)"""
+[nrounds] [seed]   (the environment value lowers the window threshold to 8 rows and takes every p <= 192)"""
 import math
 import os
 import sys
@@ -17,7 +17,7 @@ from mcmc_amd import api  # noqa: E402
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
-    p = int(rng.choice([1, 2, 7, 9, 15, 16, 17, 24, 31, 32, 33, 40, 48, 49, 63, 64]))
+    p = int(rng.choice([1, 2, 7, 9, 15, 16, 17, 24, 31, 32, 33, 40, 48, 49, 63, 64, 65, 80, 81, 96, 100, 112, 113, 128, 129, 144, 150, 160, 161, 176, 177, 192]))
     n = int(rng.choice([257, 1000, 1025, 4099, 30000, 262144, 1_048_576, 1_300_001]))
     if n * p > 12_000_000:
         n = 12_000_000 // p

@@ -826,9 +826,10 @@ def test_time_sharded_initseq_and_olbm_device_route(api, oracle_mod):
 
 
 @pytest.mark.parametrize("n,p,blen", [(40_000, 3, 1024), (150_000, 200, 5000), (66_000, 256, 1027), (1_200_000, 17, 3000),
-                                       (30_000, 64, 1500), (50_000, 129, 2048), (13_000, 256, 4000), (3_100_000, 2, 1_000_000)])
+                                       (30_000, 64, 1500), (50_000, 129, 2048), (13_000, 256, 4000), (3_100_000, 2, 1_000_000),
+                                       (30_000, 193, 1500)])
 def test_olbm_comb_route_vs_oracle(api, oracle_mod, n, p, blen):
-    """Windows of >= 1024 rows of more than 64 columns take olbm_comb.hip (x read once: teeth one window length apart swept together, window sums
+    """Windows of >= 1024 rows of more than 192 columns take olbm_comb.hip (fewer: olbm_lane.hip, olbm_small.hip, checked by name below) (x read once: teeth one window length apart swept together, window sums
     relative to the start of each piece on the matrix cores, pieces chained and rank-two terms added afterwards, exact
     means out of the chain).  Against the oracle at 1e-10 with the means supplied (the R front end's default) and
     computed by the call, and against an 80-bit evaluation of the definition at 1e-12; shapes with ragged last steps
@@ -869,7 +870,7 @@ def test_olbm_comb_route_vs_oracle(api, oracle_mod, n, p, blen):
 def _olbm_route(n, p, blen):
     """Which kernel diag.hip::run_olbm hands a shape to (olbm_small_applies / olbm_lane_applies / olbm_comb_applies)."""
     nwin = n - blen + 1
-    lane = 5 <= p <= 64 and blen >= 256 and nwin >= 4 * blen and (p > 8 or n >= 2_000_000)
+    lane = 5 <= p <= 192 and blen >= 256 and nwin >= 4 * blen and (p > 8 or n >= 2_000_000)
     if lane:
         return "olbm_lane_kernel"        # a lane per (tooth, column), no scan (olbm_lane.hip)
     if p <= 8:
@@ -880,14 +881,16 @@ def _olbm_route(n, p, blen):
 
 
 @pytest.mark.parametrize("n,p,blen", [(300_000, 9, 256), (200_000, 16, 1000), (120_000, 31, 5000), (90_000, 48, 3001),
-                                       (2_100_000, 6, 4096), (64_000, 64, 12_800), (70_001, 33, 777), (2_000_003, 5, 400_000)])
+                                       (2_100_000, 6, 4096), (64_000, 64, 12_800), (70_001, 33, 777), (2_000_003, 5, 400_000),
+                                       (40_000, 130, 1024), (30_000, 192, 700), (25_000, 100, 333), (20_000, 160, 2500)])
 def test_olbm_lane_route_vs_oracle(api, oracle_mod, n, p, blen):
-    """5 .. 64 columns and windows of >= 256 rows take olbm_lane.hip: a wave walks four teeth one window length apart with
+    """5 .. 192 columns and windows of >= 256 rows take olbm_lane.hip: a wave walks four teeth one window length apart with
     one lane per (tooth, column), window sums are running sums in registers (no scan), five rows feed four teeth, units of
     the sweep are dealt round-robin to the workgroups, pieces chained and rank-two terms added afterwards, exact means out
     of the chain.  Against the oracle at 1e-10 (1e-9 where olbm.c's own arithmetic is good for no more: windows beyond
     10 000 rows or a quarter of the series) with the means supplied and computed by the call, against an 80-bit
-    evaluation of the definition at 1e-12; every block count (16, 32, 48, 64 padded columns), a remainder tooth, a last
+    evaluation of the definition at 1e-12; block counts 1 .. 12 (odd ones: every pair of blocks with one wave; even ones:
+    the farthest pair shared between two waves), a remainder tooth, a last
     super-block of fewer than four teeth, ragged units."""
     import math
     from scipy.signal import lfilter
