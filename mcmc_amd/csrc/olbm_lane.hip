@@ -63,7 +63,7 @@ template <int NB, int TT> struct LaneShape {
 // the differences of all blocks meet in LDS, wave w accumulates the tiles (w, w), (w, w+1), .. (circulant: every unordered
 // pair of blocks once) from running sums of its own and the next H blocks.
 template <int NB, int TT>
-__global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__restrict__ x, long n, int p, long len,
+__global__ __launch_bounds__(64 * NB, (NB == 7 || NB == 8) ? 4 : 1) void olbm_lane_kernel(const double *__restrict__ x, long n, int p, long len,
                                                             const OlbmComb *__restrict__ combs,
                                                             const int *__restrict__ first, double *__restrict__ partial,
                                                             double *__restrict__ pd, double *__restrict__ pe)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * NB) void olbm_lane_kernel(const double *__rest
         for (int k = 0; k < NK; k++) D[k] += d[k];
     };
     auto walk = [&](int nst) {
-        constexpr int G = NB >= 9 ? 2 : 4;                          // steps whose differences are read ahead (registers: G NK doubles)
+        constexpr int G = NB >= 5 ? 2 : 4;                          // steps whose differences are read ahead (registers: G NK doubles)
         int i = 0;
         for (; i + G <= nst; i += G) {
             double d[G][NK];
