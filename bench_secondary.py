@@ -148,8 +148,8 @@ def c5(api, torch, dev, n=100_000_256, p=256, blen=10_000):
                                  "hbm_algorithmic_TBs": 8.0 * n * p / (kms * 1e-3) / 1e12},
                     "var_diag_over_theory": [float(var[c, c] * n / ((1 / (1 - r * r)) * (1 + r) / (1 - r))) for c, r in
                                               ((0, 0.5), (p - 1, 0.99))]})
-    # the usual call has a handful of functionals: the first 3 and the first 8 columns of the same series (olbm_small.hip)
-    for pp in (3, 8):
+    # the usual call has a handful of functionals: the first 3 (olbm_small.hip), 8 and 32 (olbm_lane.hip) columns of the same series
+    for pp in (3, 8, 32):
         m2, v2 = np.zeros(pp), np.empty((pp, pp))
         for rep in range(2):
             t0 = time.perf_counter()
@@ -162,7 +162,7 @@ def c5(api, torch, dev, n=100_000_256, p=256, blen=10_000):
                     "seconds": el, "kernel": kn, "kernel_ms": kms,
                     "roofline": {"bound": "hbm", "achieved": 8.0 * n * pp / (kms * 1e-3) / 1e12, "peak": PEAK_HBM_TBS, "unit": "TB/s",
                                  "frac": 8.0 * n * pp / (kms * 1e-3) / 1e12 / PEAK_HBM_TBS,
-                                 "note": "algorithmic bytes = the series once; the kernel reads x[t+len] and x[t]"},
+                                 "note": "algorithmic bytes = the series once; olbm_small reads x[t+len] and x[t], olbm_lane five rows for four teeth (1.25 x)"},
                     "var_diag_over_theory": [float(v2[0, 0] * n / ((1 / (1 - 0.25)) * 3.0))]})
     del x
     torch.cuda.empty_cache()
