@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ 
     long b = a + chunk;
     if (b > n) b = n;
     double s = 0.0;
+#pragma unroll 8
     for (long t = a + threadIdx.x; t < b; t += 256) s += x[(size_t)col * n + t];
     for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -37,11 +38,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ 
     if (threadIdx.x == 0) partial[(size_t)col * nchunk + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// rows per workgroup of colsum_kernel: at most 256 chunks per column, at least 16 384 rows each (one chunk of 2^20 rows left a
+// series of 1e6 rows to ONE workgroup per column, a load at a time: 1 ms of a 1.2 ms olbm call)
+static long colsum_chunk(long n)
+{
+    long c = (n + 255) / 256;
+    c = (c + 255) / 256 * 256;
+    return c < 16384 ? 16384 : c;
+}
+
 __global__ void colmean_kernel(const double *__restrict__ partial, long nchunk, long n, int p, double *__restrict__ mean)
 {
     int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= p) return;
     double s = 0.0;
+#pragma unroll 8
     for (long c = 0; c < nchunk; c++) s += partial[(size_t)col * nchunk + c];
     mean[col] = s / (double)n;     // olbm.c:42
 }
@@ -59,7 +70,7 @@ int run_series_centre(double *x, long n, long p, double *mean, DeviceCtx *dc)
 {
     hipStream_t s = dc->stream;
     if (p > 65535) return set_error(MCMCHIP_EINVAL, "too many columns");
-    const long chunk = 1 << 20, nchunk = (n + chunk - 1) / chunk;
+    const long chunk = colsum_chunk(n), nchunk = (n + chunk - 1) / chunk;
     DevBuf cpart, dmean;
     HIP_TRY(cpart.alloc((size_t)p * nchunk * 8));
     HIP_TRY(dmean.alloc((size_t)p * 8));
@@ -652,7 +663,7 @@ int olbm_pilot_centre(const double *x, long n, int p, double *dcentre, hipStream
 
 int olbm_exact_means(const double *x, long n, int p, double *dmean, hipStream_t s)
 {
-    const long chunk = 1 << 20;
+    const long chunk = colsum_chunk(n);
     const long nchunk = (n + chunk - 1) / chunk;
     DevBuf cpart;
     HIP_TRY(cpart.alloc((size_t)p * nchunk * 8));
@@ -687,7 +698,7 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
                            dcentre.as<double>());
         HIP_TRY(hipGetLastError());
     } else {
-        const long chunk = 1 << 20;
+        const long chunk = colsum_chunk(n);
         const long nchunk = (n + chunk - 1) / chunk;
         HIP_TRY(cpart.alloc((size_t)p * nchunk * 8));
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nchunk, (unsigned)p), dim3(256), 0, s, x, n, chunk, nchunk,
