@@ -9,6 +9,8 @@
 #include "kernels.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <chrono>
 #include <vector>
 
 // =============================================================================================
@@ -330,6 +332,8 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
         unit0.assign(active.size(), 0);
         units.assign(active.size(), 0);
         ssq_at.assign(active.size(), -1);
+        // units (32 lags of one column) that cost about as much as the round itself: ~30 effective TFLOP/s on the matrix cores
+        const long cheap_units = (long)(150e-6 / ((double)len * 1.1e-12 * (double)active.size()));
         for (size_t a = 0; a < active.size(); a++) {
             const int c = active[a];
             const long h = have[(size_t)c];              // pairs so far
@@ -347,10 +351,19 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
                 nb = want > 0.0 ? (long)std::ceil(want / PU) : 1;
             } else {
                 nb = (long)std::ceil((h <= 128 ? 0.4 : 0.2) * (double)h / PU);      // overshoot of the stop rule into the noise
+                // A round costs ~0.15 ms whatever it computes (launches, the reduction over the time blocks, the copy back,
+                // the host's look at the sums).  While the units asked for are cheaper than that, a column gets up to as
+                // many again as it has: a slowly mixing column of 1e6 rows took 342 launches (48 ms) in steps of 20 %.
+                const long dbl = (h + PU - 1) / PU;
+                if (nb < cheap_units) nb = std::min(cheap_units, dbl);
+                // ... and a column still going after six rounds (long memory: the rule may not fire before len / 2) grows
+                // geometrically as long as a round stays within a millisecond
+                if (rounds[(size_t)c] >= 6) nb = std::max(nb, std::min(dbl, 8 * cheap_units));
             }
             if (nb < 1) nb = 1;
             rounds[(size_t)c]++;
-            if (nb > IS_MAX_UNITS_PER_LAUNCH) nb = IS_MAX_UNITS_PER_LAUNCH;
+            const long max_units = std::max((long)IS_MAX_UNITS_PER_LAUNCH, std::min(8 * cheap_units, 4096L));
+            if (nb > max_units) nb = max_units;
             const long need = (half - h + PU - 1) / PU;            // never past pair half - 1
             if (nb > need) nb = need;
             unit0[a] = work.add(c, 2 * h, nb, true, &units[a], &ssq_at[a]);
@@ -362,7 +375,9 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
                 if (!work.items[k].empty()) fprintf(stderr, " %zu x %d%s", work.items[k].size(), IS_UNIT_LAGS * kVariants[k].nacc, kVariants[k].fam == FAM_FIRST ? "" : "c");
             fprintf(stderr, "\n");
         }
+        const auto t_round = std::chrono::steady_clock::now();
         if (int rc = run_lag_round(x, len, tg, nblk, work, bufs, host, dc)) return rc;
+        if (trace) fprintf(stderr, "[initseq] round took %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count());
         std::vector<int> next;
         for (size_t a = 0; a < active.size(); a++) {
             const int c = active[a];
