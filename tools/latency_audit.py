@@ -45,3 +45,15 @@ for (nobs, d, nchain, nbatch) in ((100, 4, 1, 1000), (100, 4, 64, 1000), (10_000
     init = np.zeros((nchain, d))
     timed("metrop logistic %d x %d, %d chain(s) x %d iterations" % (nobs, d, nchain, nbatch),
           lambda: api.metrop(tg, init, nbatch, scale=0.3 / np.sqrt(d), seed=1), reps=3)
+# temper: ONE ensemble (what the reference runs), the model-selection example of tests/temp-par.R and the witch's hat of
+# tests/temp-par-witch.R, parallel and serial
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rhelpers import temp_par_setup  # noqa: E402
+X, y, models, masks, betas, nb = temp_par_setup()
+kw = dict(x=X, y=y, prior_c=0.5, par=abi.logistic_models_par(masks))
+for parallel in (True, False):
+    tg = api.Target(abi.T_LOGISTIC_MODELS, 4, **kw)
+    init = betas if parallel else np.concatenate([[8.0], betas[7]])
+    for nbatch in (1000, 10000):
+        timed("temper %s, 8 logistic sub-models (temp-par.R), 1 ensemble x %d iterations" % ("parallel" if parallel else "serial", nbatch),
+              lambda: api.temper(tg, init, nb, nbatch, 1, 1, 0.56789, parallel=parallel, seed=3), reps=3)
