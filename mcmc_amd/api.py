@@ -583,6 +583,14 @@ def upload_series(x):
     return DeviceSeries(out.value, length, ncol)
 
 
+def _torch_ready(t):
+    """The library launches on streams of its own: work torch has queued on ITS current stream for a tensor handed over
+    (a copy, a slice made contiguous, a generator's fill) must have finished before the library reads it -- a 3.4 GB
+    `.contiguous()` was still copying its last columns when olbm started on the first."""
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
+
+
 def _colmajor(x):
     """(pointer, len, ncol, device_ptrs, keepalive) of a batch of series for the C-ABI's column-major layout x[t + len*c].
     numpy: len x ncol (or a vector); column-major (Fortran-ordered) arrays are used in place, small C-ordered ones are
@@ -593,6 +601,7 @@ def _colmajor(x):
     if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
         if not x.is_cuda or x.dim() != 2 or not x.is_contiguous() or str(x.dtype) != "torch.float64":
             raise ValueError("device series must be a contiguous float64 CUDA tensor of shape (ncol, len)")
+        _torch_ready(x)
         return x.data_ptr(), int(x.shape[1]), int(x.shape[0]), 1, x
     a = np.asarray(x, dtype=np.float64)
     if a.ndim == 1:
@@ -663,6 +672,7 @@ def chain_summary(batch, initseq=False, per_chain=False):
     if on_device:
         if not batch.is_cuda or batch.dim() != 3 or not batch.is_contiguous() or str(batch.dtype) != "torch.float64":
             raise ValueError("a device batch must be a contiguous float64 CUDA tensor of shape (nchain, nbatch, nout)")
+        _torch_ready(batch)
         ptr, keep = batch.data_ptr(), batch
     else:
         keep = np.ascontiguousarray(batch, dtype=np.float64)

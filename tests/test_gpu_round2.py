@@ -924,6 +924,61 @@ def test_olbm_lane_route_vs_oracle(api, oracle_mod, n, p, blen):
     assert np.all(np.abs(m3[:k] - exact) <= 1e-14 * np.abs(exact))
 
 
+def test_olbm_lane_series_beyond_the_32_bit_offsets(api, oracle_mod):
+    """olbm_lane.hip addresses with 64 bits: a resident series of 1.4e8 rows (beyond the 1.34e8 rows the other matrix-core
+    kernels' 32-bit byte offsets reach; they hand such a series to the fp64-FMA kernel) x 6 columns, windows of 10 000 rows.
+    Columns 0 and 5 hold the same AR(1) series: their rows of the result agree (a 32-bit offset anywhere would break that); the diagonal against the AR(1)
+    theory; the whole matrix against the time-sharded evaluation (two shards of 7e7 rows, each inside the limit) at 1e-10."""
+    import torch
+    from mcmc_amd import dist as mdist
+    dev = torch.device("cuda", 0)
+    B, n, p, blen = 512, 140_000_256, 6, 10_000
+    assert n % B == 0 and 8 * (4 * n + blen + 64) >= 1 << 32
+    x = torch.empty((p, n), dtype=torch.float64, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    s_idx = torch.arange(B, dtype=torch.float64, device=dev)
+    rhos = [0.9, 0.5, 0.7, 0.0, 0.3, 0.9]
+    for c in range(p - 1):
+        rho = rhos[c]
+        e = torch.randn((n // B, B), dtype=torch.float64, device=dev, generator=g)
+        if rho == 0.0:
+            x[c] = e.reshape(-1)
+            continue
+        w = rho ** s_idx
+        loc = torch.cumsum(e / w, dim=1) * w
+        last = loc[:, -1].clone()
+        carry = torch.zeros_like(last)
+        carry[1:] = last[:-1]
+        loc += carry[:, None] * (rho * w)[None, :]          # rho^512 = 0 in double precision for these rho
+        x[c] = loc.reshape(-1)
+        del e, loc
+    x[p - 1] = x[0]
+    x += 2.5
+    torch.cuda.synchronize()
+    var, mean = api.olbm_device(x, blen)
+    assert api.last_kernel_time()[0] == "olbm_lane_kernel"
+    # (the rank-two terms evaluate the expression of the ORDERED pair of columns, so that var is symmetric to the bit; two
+    # equal columns therefore agree to rounding, not to the bit)
+    sc = np.sqrt(np.outer(np.diag(var), np.diag(var)))
+    assert np.all(np.abs(var[0] - var[p - 1]) <= 1e-13 * sc[0]) and var[0, 0] == var[p - 1, p - 1] and mean[0] == mean[p - 1]
+    assert np.array_equal(var, var.T)
+    for c in range(p):
+        theory = (1.0 / (1.0 - rhos[c] ** 2)) * (1.0 + rhos[c]) / (1.0 - rhos[c]) / n
+        assert abs(var[c, c] / theory - 1.0) < 0.08, (c, var[c, c] / theory)
+    tot = np.zeros((p, p))
+    for r in range(2):                                       # what mcmc_amd.dist.olbm_sharded does on two ranks
+        lo, hi, own = mdist.olbm_time_shard(n, blen, r, 2)
+        assert 8 * (4 * (hi - lo) + blen + 64) < 1 << 32
+        v, _ = api.olbm_device(x[:, lo:hi].contiguous(), blen, mean=mean)
+        tot += v * (float(hi - lo - blen + 1) * (hi - lo) * blen)
+    v2 = tot / (float(n - blen + 1) * n * blen)
+    sc = np.sqrt(np.outer(np.diag(var), np.diag(var)))
+    assert np.all(np.abs(v2 - var) <= 1e-10 * sc)
+    del x
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n,p,blen", [(1_200_000, 5, 1000), (1_048_576, 70, 64), (1_100_003, 3, 1), (1_300_000, 130, 4097),
                                        (1_050_000, 2, 525_000), (1_048_581, 2, 1_048_581)])
 def test_olbm_one_pass_route_vs_oracle(api, oracle_mod, n, p, blen):
