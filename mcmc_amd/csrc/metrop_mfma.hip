@@ -466,6 +466,27 @@ __device__ __forceinline__ void make_proposal(const UpdParams &q, long c, long l
     const int d = q.d;
     const long ldc = q.ldc;
     const long niter = (long)q.nbatch * q.blen * q.nspac;
+    if (q.scale_kind == MCMCHIP_SCALE_CONSTANT || q.scale_kind == MCMCHIP_SCALE_DIAGONAL) {
+        // a pair of normals goes straight into its two coordinates (the same operations as below, without the detour of
+        // d doubles through the lane's scratch memory)
+        const bool inj = q.rng_mode == MCMCHIP_RNG_INJECTED, cst = q.scale_kind == MCMCHIP_SCALE_CONSTANT;
+        const double *zp = inj ? q.z + ((size_t)c * niter + l_next) * d : nullptr;
+        const double s0 = q.scale[0];
+        for (int j = 0; j < d; j += 2) {
+            double za, zb = 0.0;
+            if (inj) {
+                za = zp[j];
+                if (j + 1 < d) zb = zp[j + 1];
+            } else
+                philox_n2(q.seed, PHILOX_TAG_METROP, q.chain_offset + (unsigned long long)c,
+                          q.iter_offset + (unsigned long long)l_next, (uint32_t)(j / 2), za, zb);
+            q.prop[(size_t)j * ldc + c] = add_nofma(q.state[(size_t)j * ldc + c], mul_nofma(cst ? s0 : q.scale[j], za));
+            if (j + 1 < d)
+                q.prop[(size_t)(j + 1) * ldc + c] = add_nofma(q.state[(size_t)(j + 1) * ldc + c], mul_nofma(cst ? s0 : q.scale[j + 1], zb));
+        }
+        if (q.morph_flags) morph_proposal(q, c);
+        return;
+    }
     double zl[MCMCHIP_MFMA_MAXD];
     if (q.rng_mode == MCMCHIP_RNG_INJECTED) {
         const double *zp = q.z + ((size_t)c * niter + l_next) * d;
@@ -505,10 +526,10 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     const long ldc = q.ldc;
     // log density = sum_i [ (eta_i - |eta_i|)/2 - L(|eta_i|) ] - prior_c |theta|^2, with
     // sum_i eta_i = colsum . theta (eta is linear in theta) and the rest from the MFMA kernel's per-unit partials
-    // (loads in batches of 8, the sums in the same order: with few chains the kernel is one long chain of dependent loads
-    // per lane -- 256 chains, 256 units: 60 us, more than the density kernel it follows)
+    // (loads in batches of 32, the sums in the same order: with few chains the kernel is one long chain of dependent loads
+    // per lane -- 256 chains, 254 units: 60 us one load at a time, more than the density kernel it follows)
     double part = 0.0;
-#pragma unroll 8
+#pragma unroll 32
     for (int s = 0; s < q.nunits; s++) part += q.partial[(size_t)s * ldc + c];
     double ss = 0.0, lin = 0.0;
 #pragma unroll 8
@@ -571,16 +592,20 @@ __global__ __launch_bounds__(256) void metrop_update_kernel(UpdParams q, long l)
     const int jb = (int)(lb % q.blen);
     const long ib = lb / q.blen;
     if (is == q.nspac - 1) {                   // metrop.c:273-275
+        // one pass: the batch sum is loaded once and either stored back or, at the end of a batch, divided and written
+        // out (metrop.c:279-283) -- the same operations; as two loops over global memory (store, reload, divide, store)
+        // the bookkeeping took 10 of the kernel's 26 us at 256 chains
+        const bool batch_end = jb == q.blen - 1;
+        double *bo = q.batch + ((size_t)c * q.nbatch + ib) * q.nout;
+#pragma unroll 4
         for (int k = 0; k < q.nout; k++) {
             double v = q.theta_state[(size_t)q.out_map[k] * ldc + c];
             if (k >= q.sq_from) v = mul_nofma(v, v);
-            q.buf[(size_t)k * ldc + c] = add_nofma(q.buf[(size_t)k * ldc + c], v);
+            const double sum = add_nofma(q.buf[(size_t)k * ldc + c], v);
+            if (batch_end) bo[k] = sum / q.blen;
+            q.buf[(size_t)k * ldc + c] = batch_end ? 0.0 : sum;
         }
-        if (jb == q.blen - 1) {                // metrop.c:279-283
-            for (int k = 0; k < q.nout; k++) {
-                q.batch[((size_t)c * q.nbatch + ib) * q.nout + k] = q.buf[(size_t)k * ldc + c] / q.blen;
-                q.buf[(size_t)k * ldc + c] = 0.0;
-            }
+        if (batch_end) {
             q.accept_batch[(size_t)c * q.nbatch + ib] = q.acc_b[c] / ((double)q.blen * q.nspac);
             q.acc_b[c] = 0.0;
         }
