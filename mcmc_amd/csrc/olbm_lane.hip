@@ -1,4 +1,4 @@
-// olbm_lane.hip -- olbm() (reference olbm.c:22-78) for 5 .. 192 columns and windows of >= 256 rows: a wave walks FOUR TEETH of
+// olbm_lane.hip -- olbm() (reference olbm.c:22-78) for 4 .. 192 columns and windows of >= 256 rows: a wave walks FOUR TEETH of
 // a comb with one lane per (tooth, column), and nothing is scanned.
 //
 // v_mfma_f64_16x16x4_f64 takes a 16 x 4 operand: lane l supplies element (column l % 16, k = l / 16).  olbm_mfma_kernel
@@ -23,7 +23,7 @@
 // (w, w + NB/2) of the circulant, every unordered pair of blocks once (for even NB the farthest pair is shared between
 // waves w and w + NB/2, half of the steps each).  Two workgroup barriers per chunk; NB = 1 needs none.
 //
-// The plan deals units of the sweep round-robin to the workgroups (plan_units below): the chip then works inside one
+// The plan deals units of the sweep round-robin to the workgroups (LanePlan below): the chip then works inside one
 // stretch of every row and column at a time, which is what the DRAM pages and the address translation want -- 6.5 TB/s
 // of HBM traffic at p = 16 by the counters, and no slowdown for windows of 1e5 .. 1e6 rows (contiguous shares: 2 .. 2.6 x).
 #include "kernels.h"
@@ -41,6 +41,100 @@ namespace {
 // beyond 12 blocks of 16 columns a workgroup of one wave per block leaves a wave 128 registers: the accumulators of 7+ tiles,
 // the chunk in flight and the running sums do not fit (spills); 193 .. 256 columns stay with olbm_comb.hip
 #define OL_LANE_MAX_P 192
+
+// The plan in closed form (no arrays: a call of n = 1e8, p = 16 spent 0.3 - 0.7 of its 3 ms building and uploading 27 000
+// units and 110 000 piece counts).  Teeth t = 0 .. Q-1 of len windows (tooth t starts at window t * len) and one of
+// nwin % len; super-blocks of four consecutive full teeth (the last one: m_last of them) are swept together.  A
+// super-block's sweep of len windows is cut into U units of ru windows (whole multiples of 16; the last one the rest),
+// the units are numbered in time order and dealt round-robin: share g walks units g, g + nshare, ...  At any moment the
+// workgroups of the chip are then inside the same stretch of nshare * ru rows of every tooth row and column: the pages
+// and DRAM rows they touch are shared instead of one private set of 5 * 16 NB streams per wave (n = 1e8, len = 1e6 rows,
+// 64 columns: 43 ms with contiguous shares -- address translation -- against 17 ms dealt this way; len = 1e4, 16
+// columns: 3.7 against 2.6 ms).  Pieces (a unit's run of one tooth) are numbered in time order: super-block, tooth, unit.
+struct LanePlan {
+    long len, rem, Q;              // window length, nwin % len, nwin / len
+    int nsb, m_last;               // super-blocks of full teeth, teeth of the last one
+    int U, ru;                     // units per super-block, windows per unit
+    int Ur, rur;                   // the same for the remainder tooth (Ur = 0: none)
+    int nreg, nunit;               // units of the super-blocks, all units
+    int npreg, np;                 // pieces of the super-blocks, all pieces
+    int nshare;
+};
+
+__host__ __device__ inline void lane_unit(const LanePlan &P, int u, OlbmComb &c)
+{
+    if (u < P.nreg) {
+        const int sb = u / P.U, iu = u - sb * P.U;
+        c.base = (long)sb * 4 * P.len + (long)iu * P.ru;
+        c.m = sb == P.nsb - 1 ? P.m_last : 4;
+        const long rest = P.len - (long)iu * P.ru;
+        c.rlen = (int)(rest < P.ru ? rest : P.ru);
+        c.piece0 = sb * 4 * P.U + iu;
+        c.pstride = P.U;
+    } else {
+        const int iu = u - P.nreg;
+        c.base = P.Q * P.len + (long)iu * P.rur;
+        c.m = 1;
+        const long rest = P.rem - (long)iu * P.rur;
+        c.rlen = (int)(rest < P.rur ? rest : P.rur);
+        c.piece0 = P.npreg + iu;
+        c.pstride = P.Ur;
+    }
+}
+// windows of piece j and whether it starts a tooth (a window at a multiple of len)
+__host__ __device__ inline void lane_piece(const LanePlan &P, int j, int &cnt, bool &tile)
+{
+    int iu, ru;
+    long R;
+    if (j < P.npreg) { iu = j % P.U; ru = P.ru; R = P.len; }
+    else { iu = j - P.npreg; ru = P.rur; R = P.rem; }
+    const long rest = R - (long)iu * ru;
+    cnt = (int)(rest < ru ? rest : ru);
+    tile = iu == 0;
+}
+
+// units of about R windows: between 6 and 12 rounds of units per share, the candidate that wastes least of the last round
+// (more rounds: more pieces to chain afterwards)
+LanePlan make_lane_plan(long nwin, long len, long groups)
+{
+    LanePlan P{};
+    P.len = len;
+    P.Q = nwin / len;
+    P.rem = nwin % len;
+    P.nsb = (int)((P.Q + 3) / 4);
+    P.m_last = P.nsb ? (int)(P.Q - 4L * (P.nsb - 1)) : 0;
+    if (groups < 1) groups = 1;
+    const long total = (long)P.nsb * len + P.rem;
+    auto units_of = [](long rt, long R) { return R > 0 ? (R + rt - 1) / rt : 0; };
+    long best_rt = 256;
+    double best_loss = 1e30;
+    for (int k = 6; k <= 12; k++) {
+        long rt = total / (groups * k);
+        rt = (rt + 15) / 16 * 16;
+        if (rt < 256) rt = 256;
+        const long u = (long)P.nsb * units_of(rt, len) + units_of(rt, P.rem), rounds = (u + groups - 1) / groups;
+        const double loss = u > 0 ? (double)(rounds * (u < groups ? u : groups)) / (double)u : 1.0;
+        if (loss < best_loss - 1e-9) { best_loss = loss; best_rt = rt; }
+        if (rt == 256) break;
+    }
+    auto cut = [&](long R, int &U, int &ru) {                 // equal units inside a sweep of R windows
+        if (R <= 0) { U = 0; ru = 16; return; }
+        const long nu = units_of(best_rt, R);
+        long r = (R + nu - 1) / nu;
+        r = (r + 15) / 16 * 16;
+        ru = (int)r;
+        U = (int)((R + r - 1) / r);
+    };
+    cut(P.nsb ? len : 0, P.U, P.ru);
+    cut(P.rem, P.Ur, P.rur);
+    if (P.U < 1) P.U = 1;                                     // (divisor of the decode; no super-block: nreg = 0)
+    P.nreg = P.nsb ? P.nsb * P.U : 0;
+    P.nunit = P.nreg + P.Ur;
+    P.npreg = P.nsb ? ((P.nsb - 1) * 4 + P.m_last) * P.U : 0;
+    P.np = P.npreg + P.Ur;
+    P.nshare = (int)(P.nunit < groups ? P.nunit : groups);
+    return P;
+}
 
 template <int NB, int TT> struct LaneShape {
     static constexpr int PP = 16 * NB;                              // padded columns
@@ -64,8 +158,7 @@ template <int NB, int TT> struct LaneShape {
 // pair of blocks once) from running sums of its own and the next H blocks.
 template <int NB, int TT>
 __global__ __launch_bounds__(64 * NB, (NB == 7 || NB == 8) ? 4 : 1) void olbm_lane_kernel(const double *__restrict__ x, long n, int p, long len,
-                                                            const OlbmComb *__restrict__ combs,
-                                                            const int *__restrict__ first, double *__restrict__ partial,
+                                                            const LanePlan P, double *__restrict__ partial,
                                                             double *__restrict__ pd, double *__restrict__ pe)
 {
     using S = LaneShape<NB, TT>;
@@ -85,17 +178,17 @@ __global__ __launch_bounds__(64 * NB, (NB == 7 || NB == 8) ? 4 : 1) void olbm_la
     for (int q = 0; q < NK; q++) D[q] = 0.0;
 
     struct Cur { int ci, i0, m, rlen, piece0, pstride; long base; };
-    const int ci_end = __builtin_amdgcn_readfirstlane(first[g + 1]);
+    const int ci_end = P.nunit;                                     // ci: the unit; share g walks g, g + nshare, ...
     auto load_comb = [&](Cur &u) {
         u.i0 = 0;
         if (u.ci < ci_end) {
-            const OlbmComb *cb = combs + u.ci;
-            u.m = __builtin_amdgcn_readfirstlane(cb->m);
-            u.rlen = __builtin_amdgcn_readfirstlane(cb->rlen);
-            u.piece0 = __builtin_amdgcn_readfirstlane(cb->piece0);
-            u.pstride = __builtin_amdgcn_readfirstlane(cb->pstride);
-            const long b = cb->base;
-            u.base = ((long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+            OlbmComb cb;
+            lane_unit(P, u.ci, cb);                                 // uniform arithmetic
+            u.m = cb.m;
+            u.rlen = cb.rlen;
+            u.piece0 = cb.piece0;
+            u.pstride = cb.pstride;
+            u.base = cb.base;
         } else {
             u.m = 0;                                                // past the end: loads land where they did before, nothing is kept
             u.rlen = 0;
@@ -104,7 +197,7 @@ __global__ __launch_bounds__(64 * NB, (NB == 7 || NB == 8) ? 4 : 1) void olbm_la
     auto advance = [&](Cur &u) {
         u.i0 += T;
         if (u.i0 >= u.rlen) {
-            u.ci++;
+            u.ci += P.nshare;
             load_comb(u);
         }
     };
@@ -149,7 +242,7 @@ __global__ __launch_bounds__(64 * NB, (NB == 7 || NB == 8) ? 4 : 1) void olbm_la
     };
 
     Cur cur;
-    cur.ci = __builtin_amdgcn_readfirstlane(first[g]);
+    cur.ci = g;
     cur.base = 0;
     cur.m = cur.rlen = cur.piece0 = cur.pstride = 0;
     load_comb(cur);
@@ -275,87 +368,42 @@ __global__ __launch_bounds__(256) void olbm_lane_finish_kernel(const double *__r
     }
 }
 
-// The plan.  Teeth t = 0 .. Q-1 of len windows (tooth t starts at window t * len) and one of nwin % len; super-blocks of up
-// to four consecutive full teeth are swept together.  A super-block's sweep is cut into UNITS of about R windows (whole
-// multiples of 16), the units are numbered in time order and dealt round-robin: share g walks units g, g + nshare, ...
-// At any moment the workgroups of the chip are then inside the same stretch of nshare * R rows of every tooth row and
-// column: the pages and DRAM rows they touch are shared instead of one private set of 5 * 16 NB streams per wave
-// (n = 1e8, len = 1e6 rows, 64 columns: 43 ms with contiguous shares -- address translation -- against 17 ms dealt this way;
-// len = 1e4, 16 columns: 3.7 against 2.6 ms).
-// Pieces (a unit's run of one tooth) are numbered in time order: super-block, tooth, unit.
-void plan_units(long nwin, long len, long groups, CombPlan &pl)
+// piece counts and tooth starts of the plan for the chain and the rank-two kernels
+__global__ void lane_fill_pieces_kernel(const LanePlan P, int *__restrict__ pcnt, unsigned char *__restrict__ ptile)
 {
-    struct SB { long tooth0; int m; long R; };
-    std::vector<SB> sbs;
-    const long Q = nwin / len, rem = nwin % len;
-    for (long t0 = 0; t0 < Q; t0 += 4) sbs.push_back({t0, (int)(Q - t0 < 4 ? Q - t0 : 4), len});
-    if (rem) sbs.push_back({Q, 1, rem});
-    long total = 0;
-    for (auto &sb : sbs) total += sb.R;
-    auto units_of = [&](long rt, long R) { return (R + rt - 1) / rt; };
-    auto count = [&](long rt) {
-        long u = 0;
-        for (auto &sb : sbs) u += units_of(rt, sb.R);
-        return u;
-    };
-    // R: between 6 and 12 rounds of units per share, the candidate that wastes least of the last round (more rounds: more
-    // pieces to chain afterwards -- 24 rounds cost the call of n = 1e8, p = 16 half a millisecond)
-    if (groups < 1) groups = 1;
-    long best_rt = 0;
-    double best_loss = 1e30;
-    for (int k = 6; k <= 12; k++) {
-        long rt = total / (groups * k);
-        rt = (rt + 15) / 16 * 16;
-        if (rt < 256) rt = 256;
-        const long u = count(rt), rounds = (u + groups - 1) / groups;
-        const double loss = (double)(rounds * (u < groups ? u : groups)) / (double)u;
-        if (loss < best_loss - 1e-9) { best_loss = loss; best_rt = rt; }
-        if (rt == 256) break;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.np) return;
+    int cnt;
+    bool tile;
+    lane_piece(P, j, cnt, tile);
+    pcnt[j] = cnt;
+    ptile[j] = tile;
+}
+
+// the plan as arrays, share by share (for the host-side check only)
+void lane_plan_arrays(const LanePlan &P, CombPlan &pl)
+{
+    pl.npieces = P.np;
+    pl.pcnt.assign((size_t)P.np, 0);
+    pl.ptile.assign((size_t)P.np, 0);
+    for (int j = 0; j < P.np; j++) {
+        int cnt;
+        bool tile;
+        lane_piece(P, j, cnt, tile);
+        pl.pcnt[(size_t)j] = cnt;
+        pl.ptile[(size_t)j] = tile;
     }
-    const long rt = best_rt;
-    const long nunit = count(rt);
-    const long nshare = nunit < groups ? nunit : groups;
-    std::vector<OlbmComb> units;
-    units.reserve((size_t)nunit);
-    int np = 0;
-    for (auto &sb : sbs) {
-        const long nu = units_of(rt, sb.R);
-        long ru = (sb.R + nu - 1) / nu;                      // equal units inside the super-block
-        ru = (ru + 15) / 16 * 16;
-        int made = 0;
-        for (long r = 0; r < sb.R; r += ru, made++) {
-            OlbmComb c;
-            c.base = sb.tooth0 * len + r;
-            c.m = sb.m;
-            c.rlen = (int)(r + ru <= sb.R ? ru : sb.R - r);
-            c.piece0 = made;                                 // completed below
-            c.pstride = 0;
-            units.push_back(c);
-        }
-        for (size_t i = units.size() - (size_t)made; i < units.size(); i++) {
-            units[i].pstride = made;
-            units[i].piece0 += np;
-        }
-        np += sb.m * made;
-    }
-    pl.npieces = np;
-    pl.pcnt.assign((size_t)np, 0);
-    pl.ptile.assign((size_t)np, 0);
-    for (auto &c : units)
-        for (int k = 0; k < c.m; k++) {
-            const int jp = c.piece0 + k * c.pstride;
-            pl.pcnt[(size_t)jp] = c.rlen;
-            pl.ptile[(size_t)jp] = (c.base % len) == 0;
-        }
     pl.combs.clear();
     pl.first.assign(1, 0);
     pl.steps.clear();
     pl.max_steps = 0;
-    for (long g = 0; g < nshare; g++) {
+    for (int g = 0; g < P.nshare; g++) {
         long st = 0;
-        for (long u = g; u < (long)units.size(); u += nshare) {
-            pl.combs.push_back(units[(size_t)u]);
-            st += (long)units[(size_t)u].m * ((units[(size_t)u].rlen + 15) / 16);
+        for (int u = g; u < P.nunit; u += P.nshare) {
+            OlbmComb c;
+            lane_unit(P, u, c);
+            pl.combs.push_back(c);
+            st += (long)c.m * ((c.rlen + 15) / 16);
         }
         pl.first.push_back((int)pl.combs.size());
         pl.steps.push_back((int)st);
@@ -410,12 +458,9 @@ int launch_lane(const double *x, long n, int p, long len, const double *dcentre,
     static const bool dbg = getenv("MCMCHIP_OLBM_LANE_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tq[8] = {now()};
-    CombPlan pl;
-    static const bool contiguous = getenv("MCMCHIP_OLBM_LANE_PLAN") && atoi(getenv("MCMCHIP_OLBM_LANE_PLAN")) == 1;
-    if (contiguous) plan_combs(nwin, len, 4, (long)bpc * dc->num_cu, pl);       // one contiguous share per workgroup (experiments)
-    else plan_units(nwin, len, (long)bpc * dc->num_cu, pl);
+    const LanePlan P = make_lane_plan(nwin, len, (long)bpc * dc->num_cu);
     tq[1] = now();
-    const int nshare = (int)pl.steps.size(), np = pl.npieces, nchunk = olbm_chain_chunks(np);
+    const int nshare = P.nshare, np = P.np, nchunk = olbm_chain_chunks(np);
     int nsplit = (4 * dc->num_cu + S::NTT - 1) / S::NTT;
     if (nsplit > (np + 15) / 16) nsplit = (np + 15) / 16;
     if (nsplit < 1) nsplit = 1;
@@ -423,8 +468,7 @@ int launch_lane(const double *x, long n, int p, long len, const double *dcentre,
 
     const size_t sz_part = (size_t)nshare * S::NTT * 256 * 8, sz_piece = (size_t)np * S::PP * 8,
                  sz_small = ((size_t)2 * nchunk + 4) * S::PP * 8, sz_red = (size_t)nsplit * S::NTT * 256 * 8;
-    const size_t o_combs = 0, o_first = o_combs + pl.combs.size() * sizeof(OlbmComb), o_pcnt = o_first + pl.first.size() * 4,
-                 o_ptile = o_pcnt + (size_t)np * 4, sz_plan = o_ptile + (size_t)np;
+    const size_t o_pcnt = 0, o_ptile = o_pcnt + (size_t)np * 4, sz_plan = o_ptile + (size_t)np;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     HIP_TRY(K.all.alloc(up(sz_part) + 2 * up(sz_piece) + up(sz_small) + up(sz_red) + up(sz_plan)));
     tq[2] = now();
@@ -436,13 +480,9 @@ int launch_lane(const double *x, long n, int p, long len, const double *dcentre,
     K.small = (double *)carve(sz_small);
     K.red = (double *)carve(sz_red);
     char *pb = carve(sz_plan);
-    std::vector<char> hplan(sz_plan);
-    memcpy(hplan.data() + o_combs, pl.combs.data(), pl.combs.size() * sizeof(OlbmComb));
-    memcpy(hplan.data() + o_first, pl.first.data(), pl.first.size() * 4);
-    memcpy(hplan.data() + o_pcnt, pl.pcnt.data(), (size_t)np * 4);
-    memcpy(hplan.data() + o_ptile, pl.ptile.data(), (size_t)np);
-    HIP_TRY(hipMemcpyAsync(pb, hplan.data(), sz_plan, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));                       // hplan goes out of scope
+    hipLaunchKernelGGL(lane_fill_pieces_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, P, (int *)(pb + o_pcnt),
+                       (unsigned char *)(pb + o_ptile));
+    HIP_TRY(hipGetLastError());
     tq[3] = now();
     K.nshare = nshare;
     K.np = np;
@@ -454,8 +494,7 @@ int launch_lane(const double *x, long n, int p, long len, const double *dcentre,
 
     timing_reset("olbm_lane_kernel");
     timing_begin(s);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nshare), dim3(64 * NB), S::lds_bytes, s, x, n, p, len,
-                       (const OlbmComb *)(pb + o_combs), (const int *)(pb + o_first), K.part, K.pd, K.pe);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nshare), dim3(64 * NB), S::lds_bytes, s, x, n, p, len, P, K.part, K.pd, K.pe);
     timing_end(s);
     HIP_TRY(hipGetLastError());
     if (dbg) { (void)hipStreamSynchronize(s); tq[4] = now(); }
@@ -465,21 +504,22 @@ int launch_lane(const double *x, long n, int p, long len, const double *dcentre,
     if (dbg) {
         (void)hipStreamSynchronize(s);
         tq[5] = now();
-        fprintf(stderr, "olbm_lane: shares %d units %zu pieces %d | plan %.3f alloc %.3f upload %.3f kernel %.3f post %.3f ms\n", nshare,
-                pl.combs.size(), np, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
+        fprintf(stderr, "olbm_lane: shares %d units %d pieces %d | plan %.3f alloc %.3f fill %.3f kernel %.3f post %.3f ms\n", nshare,
+                P.nunit, np, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
     }
     return rcf;
 }
 
 }  // namespace
 
-// Host-only check of plan_units (no GPU call; tests/test_host_cpu.py), as mcmchip_olbm_comb_plan_check
+// Host-only check of the plan (no GPU call; tests/test_host_cpu.py), as mcmchip_olbm_comb_plan_check: the arrays are made
+// by the same decode functions the kernels use
 extern "C" int mcmchip_olbm_lane_plan_check(int64_t nwin, int64_t len, int64_t groups, int32_t *npieces, int64_t *min_steps,
                                             int64_t *max_steps)
 {
     if (nwin < 1 || len < 1 || groups < 1) return -1;
     CombPlan pl;
-    plan_units((long)nwin, (long)len, (long)groups, pl);
+    lane_plan_arrays(make_lane_plan((long)nwin, (long)len, (long)groups), pl);
     long lo = 0, hi = 0;
     const int bad = olbm_plan_violations(pl, (long)nwin, (long)len, 4, npieces, &lo, &hi);
     if (min_steps) *min_steps = lo;
@@ -491,14 +531,14 @@ bool olbm_lane_applies(long n, int p, long len)
 {
     static const char *env = getenv("MCMCHIP_OLBM_LANE");
     if (env && env[0] == '0') return false;
-    // Measured at n = 1e8, len = 1e4 (ms per call, this kernel / what served before): p = 5: 2.3 / 3.1 (olbm_small), p = 8:
-    // 2.4 / 6.0, p = 9: 2.5 / 14.5 (olbm_mfma_kernel), p = 16: 3.1 / 14.6, p = 32: 6.2 / 15.9, p = 64: 15.7 / 22.3, p = 65: 23.9 / 45.0
-    // (olbm_comb_kernel), p = 128: 43.7 / 46.5, p = 129: 65.4 / 113.1, p = 192: 81.2 / 113.6; p <= 4 stays with olbm_small
-    // (p = 4: 2.65 / 2.3), and so does a short series of few columns (the plan and the chain cost 0.5 ms).
+    // Measured at n = 1e8, len = 1e4 (ms per call, this kernel / what served before): p = 4: 1.8 / 2.3 (olbm_small), p = 5: 1.9 / 3.0,
+    // p = 8: 2.1 / 6.0, p = 9: 2.1 / 14.4 (olbm_mfma_kernel), p = 16: 2.7 / 14.5, p = 32: 5.8 / 15.6, p = 64: 15.4 / 22.4, p = 65: 24.2 / 44.7
+    // (olbm_comb_kernel), p = 128: 41.4 / 46.2, p = 129: 64.7 / 111.5, p = 192: 80.3 / 112.0; p <= 3 stays with olbm_small
+    // (p = 3: 1.8 / 1.6), and so does a series of fewer than 1e6 rows of few columns (n = 1e5, p = 8: 0.27 / 0.11 ms per call).
     // MCMCHIP_OLBM_LANE=<min len> lowers the window threshold and takes every p <= 192 (tests/fuzz_olbm_lane.py).
     long min_len = 256;
-    int min_p = 5;
-    long min_n_few = 2000000;
+    int min_p = 4;
+    long min_n_few = 1000000;
     if (env && atol(env) > 1) { min_len = atol(env); min_p = 1; min_n_few = 0; }
     const long nwin = n - len + 1;
     if (p <= 8 && n < min_n_few) return false;

@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("MCMCHIP_OLBM_LANE", "0")      # p = 4 .. 8 with long windows of a long series would take olbm_lane.hip
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402

@@ -870,7 +870,7 @@ def test_olbm_comb_route_vs_oracle(api, oracle_mod, n, p, blen):
 def _olbm_route(n, p, blen):
     """Which kernel diag.hip::run_olbm hands a shape to (olbm_small_applies / olbm_lane_applies / olbm_comb_applies)."""
     nwin = n - blen + 1
-    lane = 5 <= p <= 192 and blen >= 256 and nwin >= 4 * blen and (p > 8 or n >= 2_000_000)
+    lane = 4 <= p <= 192 and blen >= 256 and nwin >= 4 * blen and (p > 8 or n >= 1_000_000)
     if lane:
         return "olbm_lane_kernel"        # a lane per (tooth, column), no scan (olbm_lane.hip)
     if p <= 8:
@@ -882,9 +882,10 @@ def _olbm_route(n, p, blen):
 
 @pytest.mark.parametrize("n,p,blen", [(300_000, 9, 256), (200_000, 16, 1000), (120_000, 31, 5000), (90_000, 48, 3001),
                                        (2_100_000, 6, 4096), (64_000, 64, 12_800), (70_001, 33, 777), (2_000_003, 5, 400_000),
-                                       (40_000, 130, 1024), (30_000, 192, 700), (25_000, 100, 333), (20_000, 160, 2500)])
+                                       (40_000, 130, 1024), (30_000, 192, 700), (25_000, 100, 333), (20_000, 160, 2500),
+                                       (1_000_000, 4, 999)])
 def test_olbm_lane_route_vs_oracle(api, oracle_mod, n, p, blen):
-    """5 .. 192 columns and windows of >= 256 rows take olbm_lane.hip: a wave walks four teeth one window length apart with
+    """4 .. 192 columns (up to 8 only from 1e6 rows on) and windows of >= 256 rows take olbm_lane.hip: a wave walks four teeth one window length apart with
     one lane per (tooth, column), window sums are running sums in registers (no scan), five rows feed four teeth, units of
     the sweep are dealt round-robin to the workgroups, pieces chained and rank-two terms added afterwards, exact means out
     of the chain.  Against the oracle at 1e-10 (1e-9 where olbm.c's own arithmetic is good for no more: windows beyond
