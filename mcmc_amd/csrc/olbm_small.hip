@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void olbm_small_finish_kernel(const double *__
 #pragma unroll
     for (int c = 0; c < P; c++) {
         double sm = 0.0;
+#pragma unroll 8
         for (int j = j0; j < j1; j++) sm += rec[(size_t)j * NREC + NPAIR + P + c];
         csum[c][t] = sm;
     }
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(256) void olbm_small_finish_kernel(const double *__
         for (int i = 0; i < a; i++) idx += P - i;
         idx += b - a;
         double s = 0.0;
-        for (int j = 0; j < npiece; j++) {
+#pragma unroll 8
+        for (int j = 0; j < npiece; j++) {                              // (loads in batches, the sum in piece order)
             const double *r = rec + (size_t)j * NREC;
             const double sa = shift[a] + sig[(size_t)j * P + a], sb = shift[b] + sig[(size_t)j * P + b];
             const double tt = fma(r[NPAIR + 3 * P + 1], sa, r[NPAIR + a]);
