@@ -360,8 +360,8 @@ int mcmchip_series_centre(double *dev, int64_t n, int64_t p, double *mean);
  * rounded to an ulp, where the reference's sequential sum is good to ~sqrt(n) ulp).
  * p <= 8 runs as a stream on the vector units (olbm_small.hip: 0.4 - 5 ms per 1e8 rows; MCMCHIP_OLBM_SMALL=0 keeps the
  * matrix-core kernel).
- * 4 <= p <= 192 with windows of >= 256 rows (at least four window lengths of windows; p <= 8 only from 1e6 rows on) runs on
- * the matrix cores with one lane per (tooth, column) and no scan (olbm_lane.hip: 1.5 ms (p = 4) .. 14 ms (p = 64) .. 79 ms
+ * 3 <= p <= 192 with windows of >= 256 rows (at least four window lengths of windows; p <= 8 only from n p = 4e7 on) runs on
+ * the matrix cores with one lane per (tooth, column) and no scan (olbm_lane.hip: 0.8 ms (p = 4) .. 14 ms (p = 64) .. 79 ms
  * (p = 192) per 1e8 rows, 1.25 x the input read; MCMCHIP_OLBM_LANE=0 keeps the kernels that served before).
  * Windows of >= 1024 rows of 193 .. 256 columns (at least two window lengths of windows) are computed with x read once
  * instead of twice (olbm_comb.hip; MCMCHIP_OLBM_COMB=0 keeps the two-stream kernel).
@@ -384,6 +384,9 @@ int mcmchip_olbm_comb_plan_check(int64_t nwin, int64_t len, int32_t teeth, int64
  * workgroups).  Host-only, no counterpart in the reference. */
 int mcmchip_olbm_lane_plan_check(int64_t nwin, int64_t len, int64_t groups, int32_t *npieces, int64_t *min_steps,
                                  int64_t *max_steps);
+/* ... and for p <= 8, where `sub` = 2 or 4 consecutive units of that plan share an instruction (olbm_few_kernel). */
+int mcmchip_olbm_few_plan_check(int64_t nwin, int64_t len, int64_t groups, int32_t sub, int32_t *npieces, int64_t *min_steps,
+                                int64_t *max_steps);
 
 /* Cross-chain diagnostics -- NO COUNTERPART IN THE REFERENCE, which runs one chain (its users read colMeans(out$batch)
  * and apply(out$batch, 2, sd) / sqrt(out$nbatch), vignettes/demo.Rnw:210-222).  A batched call returns nchain x nbatch x

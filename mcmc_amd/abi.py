@@ -155,6 +155,7 @@ EXPORTS = [
     "mcmchip_initseq",
     "mcmchip_olbm_comb_plan_check",
     "mcmchip_olbm_lane_plan_check",
+    "mcmchip_olbm_few_plan_check",
     "mcmchip_lagsums",
     "mcmchip_initseq_from_lagsums",
     "mcmchip_olbm",

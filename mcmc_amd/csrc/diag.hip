@@ -679,7 +679,7 @@ int run_olbm(const double *x, long n, int p, long len, double *mean, double *var
 {
     hipStream_t s = dc->stream;
     if (n >= (1L << 31)) return set_error(MCMCHIP_EINVAL, "olbm: n exceeds the reference's int range (olbm.c:25)");
-    if (olbm_lane_applies(n, p, len)) return run_olbm_lane(x, n, p, len, mean, var, nocalc, dc);   // 4 .. 192 columns, long windows: olbm_lane.hip
+    if (olbm_lane_applies(n, p, len)) return run_olbm_lane(x, n, p, len, mean, var, nocalc, dc);   // 3 .. 192 columns, long windows: olbm_lane.hip
     if (olbm_small_applies(n, p, len)) return run_olbm_small(x, n, p, len, mean, var, nocalc, dc); // few columns: olbm_small.hip
     if (olbm_comb_applies(n, p, len)) return run_olbm_comb(x, n, p, len, mean, var, nocalc, dc);   // long windows: olbm_comb.hip
     DevBuf dmean, dvar, part, cpart, dcentre, ddelta;

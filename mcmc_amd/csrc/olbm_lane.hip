@@ -1,4 +1,4 @@
-// olbm_lane.hip -- olbm() (reference olbm.c:22-78) for 4 .. 192 columns and windows of >= 256 rows: a wave walks FOUR TEETH of
+// olbm_lane.hip -- olbm() (reference olbm.c:22-78) for 3 .. 192 columns and windows of >= 256 rows: a wave walks FOUR TEETH of
 // a comb with one lane per (tooth, column), and nothing is scanned.
 //
 // v_mfma_f64_16x16x4_f64 takes a 16 x 4 operand: lane l supplies element (column l % 16, k = l / 16).  olbm_mfma_kernel
@@ -93,9 +93,10 @@ __host__ __device__ inline void lane_piece(const LanePlan &P, int j, int &cnt, b
     tile = iu == 0;
 }
 
-// units of about R windows: between 6 and 12 rounds of units per share, the candidate that wastes least of the last round
-// (more rounds: more pieces to chain afterwards)
-LanePlan make_lane_plan(long nwin, long len, long groups)
+// units of about R windows: between 6 and 12 rounds per share, the candidate whose busiest share sweeps the fewest windows
+// (more rounds: more pieces to chain afterwards).  sub > 1 (olbm_few_kernel): sub consecutive units of a sweep form a
+// bundle, and it is bundles that are dealt.
+LanePlan make_lane_plan(long nwin, long len, long groups, int sub = 1)
 {
     LanePlan P{};
     P.len = len;
@@ -105,28 +106,32 @@ LanePlan make_lane_plan(long nwin, long len, long groups)
     P.m_last = P.nsb ? (int)(P.Q - 4L * (P.nsb - 1)) : 0;
     if (groups < 1) groups = 1;
     const long total = (long)P.nsb * len + P.rem;
-    auto units_of = [](long rt, long R) { return R > 0 ? (R + rt - 1) / rt : 0; };
-    long best_rt = 256;
-    double best_loss = 1e30;
-    for (int k = 6; k <= 12; k++) {
-        long rt = total / (groups * k);
-        rt = (rt + 15) / 16 * 16;
-        if (rt < 256) rt = 256;
-        const long u = (long)P.nsb * units_of(rt, len) + units_of(rt, P.rem), rounds = (u + groups - 1) / groups;
-        const double loss = u > 0 ? (double)(rounds * (u < groups ? u : groups)) / (double)u : 1.0;
-        if (loss < best_loss - 1e-9) { best_loss = loss; best_rt = rt; }
-        if (rt == 256) break;
-    }
-    auto cut = [&](long R, int &U, int &ru) {                 // equal units inside a sweep of R windows
+    auto cut = [](long rt, long R, int &U, int &ru) {         // equal units inside a sweep of R windows
         if (R <= 0) { U = 0; ru = 16; return; }
-        const long nu = units_of(best_rt, R);
+        const long nu = (R + rt - 1) / rt;
         long r = (R + nu - 1) / nu;
         r = (r + 15) / 16 * 16;
         ru = (int)r;
         U = (int)((R + r - 1) / r);
     };
-    cut(P.nsb ? len : 0, P.U, P.ru);
-    cut(P.rem, P.Ur, P.rur);
+    auto bundles = [sub](int U, int ru, long R) { return (long)((U + sub - 1) / sub); };      // of a sweep: its units in groups of sub
+    long best_rt = 256;
+    double best_cost = 1e300;
+    for (int k = sub > 1 ? 4 : 6; k <= (sub > 1 ? 8 : 12); k++) {
+        long rt = total / (groups * k * sub);
+        rt = (rt + 15) / 16 * 16;
+        if (rt < 256) rt = 256;
+        int U, ru, Ur, rur;
+        cut(rt, P.nsb ? len : 0, U, ru);
+        cut(rt, P.rem, Ur, rur);
+        const long nb = (long)P.nsb * bundles(U, ru, len) + bundles(Ur, rur, P.rem);
+        const long rounds = (nb + groups - 1) / groups;
+        const double cost = (double)rounds * (double)(ru > rur || !Ur ? ru : rur);      // windows the busiest share sweeps
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best_rt = rt; }
+        if (rt == 256) break;
+    }
+    cut(best_rt, P.nsb ? len : 0, P.U, P.ru);
+    cut(best_rt, P.rem, P.Ur, P.rur);
     if (P.U < 1) P.U = 1;                                     // (divisor of the decode; no super-block: nreg = 0)
     P.nreg = P.nsb ? P.nsb * P.U : 0;
     P.nunit = P.nreg + P.Ur;
@@ -411,9 +416,300 @@ void lane_plan_arrays(const LanePlan &P, CombPlan &pl)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// p <= 8: several units side by side in one instruction
+// ---------------------------------------------------------------------------------------------
+// With 16 column slots per instruction and p <= 8 (<= 4) columns, half (three quarters) of every MFMA would multiply
+// padding: at p <= 8 the walk above is bound by the matrix pipe, not by HBM (1.5 ms per 1e8 rows whatever p is).  Here
+// the 16 slots hold SUB = 16 / CG consecutive UNITS of the plan side by side (CG = 4 or 8 columns each): lane
+// (tooth j, slot v) walks unit u0 + v / CG of a bundle, column v % CG.  The diagonal CG x CG blocks of the 16 x 16
+// accumulator are the units' sums (the off-diagonal blocks, products across units, are dropped); units, pieces, chain
+// and rank-two terms are the plan's, unchanged.  Only the sweep's last unit can be shorter than the others of its bundle:
+// the chunks in which it has ended give its lanes a zero operand.
+struct FewPlan {
+    LanePlan L;
+    int SUB;                       // units side by side
+    int B, Br;                     // bundles of a super-block's sweep, of the remainder tooth's
+    int nbund, nshare;
+};
+
+// bundle b: units u0 .. u0 + nsub - 1 of one sweep, ustride windows apart, rlen steps; the sweep's last unit may be
+// shorter than the others: member short_s then has only short_len windows (short_s = -1: none)
+__host__ __device__ inline void few_bundle(const FewPlan &F, int b, OlbmComb &c, int &nsub, int &ustride, int &short_s, int &short_len)
+{
+    const LanePlan &P = F.L;
+    const int nregb = P.nsb * F.B;
+    const bool reg = b < nregb;
+    const int sb = reg ? b / F.B : 0, ib = reg ? b - sb * F.B : b - nregb;
+    const int U = reg ? P.U : P.Ur, ru = reg ? P.ru : P.rur;
+    const long R = reg ? P.len : P.rem;
+    const int u0 = ib * F.SUB;
+    nsub = U - u0 < F.SUB ? U - u0 : F.SUB;
+    const int last_len = (int)(R - (long)(U - 1) * ru);       // of the sweep's last unit (<= ru)
+    const bool has_last = u0 + nsub == U;
+    c.rlen = has_last && nsub == 1 ? last_len : ru;
+    short_s = has_last && last_len < c.rlen ? nsub - 1 : -1;
+    short_len = last_len;
+    ustride = ru;
+    if (reg) {
+        c.base = (long)sb * 4 * P.len + (long)u0 * ru;
+        c.m = sb == P.nsb - 1 ? P.m_last : 4;
+        c.piece0 = sb * 4 * P.U + u0;
+        c.pstride = P.U;
+    } else {
+        c.base = P.Q * P.len + (long)u0 * ru;
+        c.m = 1;
+        c.piece0 = P.npreg + u0;
+        c.pstride = P.Ur;
+    }
+}
+
+FewPlan make_few_plan(long nwin, long len, long groups, int sub)
+{
+    FewPlan F{};
+    F.SUB = sub;
+    F.L = make_lane_plan(nwin, len, groups, sub);
+    const LanePlan &P = F.L;
+    F.B = P.nsb ? (P.U + sub - 1) / sub : 1;                  // (1: divisor of the decode)
+    F.Br = (P.Ur + sub - 1) / sub;
+    F.nbund = (P.nsb ? P.nsb * F.B : 0) + F.Br;
+    long shares = F.nbund / 3;                                // at least three bundles a share: a share more or less is then 33 % at worst
+    if (shares < 1) shares = 1;
+    F.nshare = (int)(shares < groups ? shares : groups);
+    return F;
+}
+
+// the plan as arrays, share by share (for the host-side check only)
+void few_plan_arrays(const FewPlan &F, CombPlan &pl)
+{
+    const LanePlan &P = F.L;
+    pl.npieces = P.np;
+    pl.pcnt.assign((size_t)P.np, 0);
+    pl.ptile.assign((size_t)P.np, 0);
+    for (int j = 0; j < P.np; j++) {
+        int cnt;
+        bool tile;
+        lane_piece(P, j, cnt, tile);
+        pl.pcnt[(size_t)j] = cnt;
+        pl.ptile[(size_t)j] = tile;
+    }
+    pl.combs.clear();
+    pl.first.assign(1, 0);
+    pl.steps.clear();
+    pl.max_steps = 0;
+    for (int g = 0; g < F.nshare; g++) {
+        long st = 0;
+        for (int b = g; b < F.nbund; b += F.nshare) {
+            OlbmComb c;
+            int nsub, ustride, short_s, short_len;
+            few_bundle(F, b, c, nsub, ustride, short_s, short_len);
+            for (int q = 0; q < nsub; q++) {
+                OlbmComb d = c;
+                d.base += (long)q * ustride;
+                d.piece0 += q;
+                if (q == short_s) d.rlen = short_len;
+                pl.combs.push_back(d);
+                st += (long)d.m * ((d.rlen + 15) / 16);
+            }
+        }
+        pl.first.push_back((int)pl.combs.size());
+        pl.steps.push_back((int)st);
+        if (st > pl.max_steps) pl.max_steps = st;
+    }
+}
+
+template <int CG>
+__global__ __launch_bounds__(64) void olbm_few_kernel(const double *__restrict__ x, long n, int p, long len, const FewPlan F,
+                                                      double *__restrict__ partial, double *__restrict__ pd,
+                                                      double *__restrict__ pe)
+{
+    constexpr int T = 16, TP = T + 1;
+    __shared__ double W[4 * 16 * TP];                               // [tooth][slot][TP]
+    const int lane = threadIdx.x, g = blockIdx.x;
+    const int j = lane >> 4, v = lane & 15, su = v / CG, col = v % CG;   // the walk: tooth, slot = (unit of the bundle, column)
+    const int li = lane & 15, lseg = lane >> 4;                     // the loads: step inside the chunk, slot run
+    om_double4 acc = om_double4{0.0, 0.0, 0.0, 0.0};
+    double D = 0.0, dsum = 0.0;
+
+    struct Cur { int b, i0, m, rlen, nsub, piece0, pstride, ustride, short_s, short_len; long base; };
+    auto load_bundle = [&](Cur &u) {
+        u.i0 = 0;
+        if (u.b < F.nbund) {
+            OlbmComb c;
+            few_bundle(F, u.b, c, u.nsub, u.ustride, u.short_s, u.short_len);   // uniform arithmetic
+            u.m = c.m;
+            u.rlen = c.rlen;
+            u.piece0 = c.piece0;
+            u.pstride = c.pstride;
+            u.base = c.base;
+        } else {
+            u.m = 0;                                                // past the end: loads land somewhere valid, nothing is kept
+            u.rlen = 0;
+            u.nsub = 0;
+            u.short_s = -1;
+        }
+    };
+    auto advance = [&](Cur &u) {
+        u.i0 += T;
+        if (u.i0 >= u.rlen) {
+            u.b += F.nshare;
+            load_bundle(u);
+        }
+    };
+    int sk[4], ck[4];
+    size_t colpart[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int vk = 4 * k + lseg;
+        sk[k] = vk / CG;
+        ck[k] = vk % CG;
+        colpart[k] = (size_t)(ck[k] < p ? ck[k] : p - 1) * (size_t)n;
+    }
+    double st[5][4];                                                // the chunk in flight: rows of tooth 0 .. 4
+    auto issue = [&](const Cur &u) {
+        const long tb = u.base + u.i0 + li;
+#pragma unroll
+        for (int jj = 0; jj < 5; jj++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                long t = tb + jj * len + (long)sk[k] * u.ustride;
+                t = t < n ? t : n - 1;
+                st[jj][k] = x[colpart[k] + t];
+            }
+    };
+    double *Wc = W + lseg * TP + li;
+    auto commit = [&](const Cur &u) {
+        const long tb = u.base + u.i0 + li;
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool ok = jt < u.m && sk[k] < u.nsub && ck[k] < p && tb + (jt + 1) * len + (long)sk[k] * u.ustride < n &&
+                                (sk[k] != u.short_s || u.i0 + li < u.short_len);      // past the end of a shorter last unit: nothing
+                Wc[(jt * 16 + 4 * k) * TP] = ok ? st[jt + 1][k] - st[jt][k] : 0.0;    // (olbm.c:60: the last window adds nothing)
+            }
+    };
+    auto sync = [&]() {                                             // one wave: LDS operations complete in order
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    Cur cur;
+    cur.b = g;
+    cur.base = 0;
+    cur.m = cur.rlen = cur.nsub = cur.piece0 = cur.pstride = cur.ustride = cur.short_len = 0;
+    cur.short_s = -1;
+    load_bundle(cur);
+    issue(cur);
+    const double *Wr = W + (j * 16 + v) * TP;
+    while (cur.b < F.nbund) {
+        commit(cur);
+        sync();
+        Cur nxt = cur;
+        advance(nxt);
+        issue(nxt);
+        int nst = cur.rlen - cur.i0;
+        nst = nst < T ? nst : T;
+        int i = 0;
+        if (cur.short_s >= 0 && cur.i0 + nst > cur.short_len) {
+            // the chunk in which a shorter last unit ends (and those after it): its lanes take part with a zero operand from
+            // there on -- their running sum stays what it was at the end (the piece's e), their differences are zero
+            const int end = su == cur.short_s ? cur.short_len - cur.i0 : nst;
+            for (; i < nst; i++) {
+                const double d = Wr[i];
+                const double Dl = i < end ? D : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dl, Dl, acc, 0, 0, 0);
+                dsum += Dl;
+                D += d;
+            }
+        }
+        for (; i + 4 <= nst; i += 4) {
+            double d[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) d[q] = Wr[i + q];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D, D, acc, 0, 0, 0);
+                dsum += D;
+                D += d[q];
+            }
+        }
+        for (; i < nst; i++) {
+            const double d = Wr[i];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D, D, acc, 0, 0, 0);
+            dsum += D;
+            D += d;
+        }
+        if (cur.i0 + T >= cur.rlen) {                               // the bundle is done: its pieces' d and e
+            if (j < cur.m && su < cur.nsub && col < p) {
+                const size_t at = (size_t)(cur.piece0 + su + j * cur.pstride) * CG + col;
+                pd[at] = dsum;
+                pe[at] = D;
+            }
+            dsum = 0.0;
+            D = 0.0;
+        }
+        sync();
+        cur = nxt;
+    }
+    double *out = partial + (size_t)g * 256;
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[r * 64 + lane] = acc[r];
+}
+
+// one split of the shares' accumulators (all 256 entries) and, by the first CG x CG threads, one split of the pieces'
+// rank-two terms for the ordered pair of columns
+template <int CG>
+__global__ __launch_bounds__(256) void olbm_few_reduce_kernel(const double *__restrict__ partial, int nshare, int share_split,
+                                                              const double *__restrict__ pe, const double *__restrict__ pd,
+                                                              const int *__restrict__ pcnt, int npieces, int per_split,
+                                                              const double *__restrict__ shift, double *__restrict__ red,
+                                                              double *__restrict__ redc)
+{
+    const int e = threadIdx.x, b = blockIdx.x;
+    double s = 0.0;
+    const int g0 = b * share_split, g1 = g0 + share_split < nshare ? g0 + share_split : nshare;
+#pragma unroll 8
+    for (int g = g0; g < g1; g++) s += partial[(size_t)g * 256 + e];
+    red[(size_t)b * 256 + e] = s;
+    if (e < CG * CG) {
+        const int a = e / CG, c = e % CG, ia = a < c ? a : c, ib = a < c ? c : a;
+        const double sha = shift[ia], shb = shift[ib];
+        const int j0 = b * per_split, j1 = j0 + per_split < npieces ? j0 + per_split : npieces;
+        double cs = 0.0;
+#pragma unroll 8
+        for (int jp = j0; jp < j1; jp++) {
+            const double sa = sha + pe[(size_t)jp * CG + ia], sb = shb + pe[(size_t)jp * CG + ib];
+            const double da = pd[(size_t)jp * CG + ia], db = pd[(size_t)jp * CG + ib];
+            const double tt = fma((double)pcnt[jp], sa, da);
+            cs = fma(tt, sb, cs);
+            cs = fma(sa, db, cs);
+        }
+        redc[(size_t)b * CG * CG + e] = cs;
+    }
+}
+
+template <int CG>
+__global__ __launch_bounds__(64) void olbm_few_finish_kernel(const double *__restrict__ red, const double *__restrict__ redc,
+                                                             int nsplit, int p, double denom, double *__restrict__ var)
+{
+    const int e = threadIdx.x;
+    if (e >= CG * CG) return;
+    const int a = e / CG, c = e % CG;
+    double s = 0.0;
+    for (int q = 0; q < 16 / CG; q++) {                                // the units' diagonal blocks of the accumulator
+        const int row = q * CG + a, colm = q * CG + c, idx = (row >> 2) * 64 + (row & 3) * 16 + colm;
+#pragma unroll 8
+        for (int b = 0; b < nsplit; b++) s += red[(size_t)b * 256 + idx];
+    }
+    double cs = 0.0;
+#pragma unroll 8
+    for (int b = 0; b < nsplit; b++) cs += redc[(size_t)b * CG * CG + e];
+    if (a < p && c < p) var[a + (size_t)p * c] = (s + cs) / denom;     // olbm.c:74-75
+}
+
 struct LaneState {
     DevBuf all;
-    double *part = nullptr, *pd = nullptr, *pe = nullptr, *small = nullptr, *red = nullptr;
+    double *part = nullptr, *pd = nullptr, *pe = nullptr, *small = nullptr, *red = nullptr, *redc = nullptr;
     int nshare = 0, np = 0, nchunk = 0, nsplit = 0, per_split = 0, share_split = 0;
     int *dpcnt = nullptr;
 };
@@ -510,6 +806,82 @@ int launch_lane(const double *x, long n, int p, long len, const double *dcentre,
     return rcf;
 }
 
+template <int CG>
+int finish_few(const double *x, long n, int p, long len, const double *dcentre, double *dmean_out, double *ddelta, double *dvar,
+               DeviceCtx *dc, LaneState &K)
+{
+    hipStream_t s = dc->stream;
+    const long nwin = n - len + 1;
+    double *csum = K.small, *tsum = csum + (size_t)K.nchunk * CG, *s0 = tsum + (size_t)K.nchunk * CG, *tail = s0 + CG, *shift = tail + CG;
+    if (int rc = olbm_first_window_sums(x, n, p, len, dcentre, s0, tail, s)) return rc;
+    if (int rc = olbm_chain_means(tsum, K.nchunk, CG, p, s0, tail, dcentre, n, len, dmean_out ? 1 : 0, dmean_out, ddelta, shift, s))
+        return rc;
+    hipLaunchKernelGGL(olbm_few_reduce_kernel<CG>, dim3((unsigned)K.nsplit), dim3(256), 0, s, K.part, K.nshare, K.share_split, K.pe,
+                       K.pd, K.dpcnt, K.np, K.per_split, shift, K.red, K.redc);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(olbm_few_finish_kernel<CG>, dim3(1), dim3(64), 0, s, K.red, K.redc, K.nsplit, p,
+                       (double)nwin * (double)n * (double)len, dvar);
+    HIP_TRY(hipGetLastError());
+    return MCMCHIP_OK;
+}
+
+template <int CG>
+int launch_few(const double *x, long n, int p, long len, const double *dcentre, double *dmean_out, double *ddelta, double *dvar,
+               DeviceCtx *dc, LaneState &K)
+{
+    hipStream_t s = dc->stream;
+    const long nwin = n - len + 1;
+    auto kern = olbm_few_kernel<CG>;
+    int bpc = 1;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, reinterpret_cast<const void *>(kern), 64, 0));
+    if (bpc < 1) bpc = 1;
+    if (bpc > 8) bpc = 8;                                           // two waves per SIMD keep HBM busy; more shares are more pieces to chain
+    if (const char *e = getenv("MCMCHIP_OLBM_LANE_GROUPS")) {       // workgroups per CU (experiments)
+        const long v = atol(e);
+        if (v >= 1 && v <= 64) bpc = (int)v;
+    }
+    const FewPlan F = make_few_plan(nwin, len, (long)bpc * dc->num_cu, 16 / CG);
+    const int nshare = F.nshare, np = F.L.np, nchunk = olbm_chain_chunks(np);
+    int nsplit = 2 * dc->num_cu;
+    if (nsplit > (np + 15) / 16) nsplit = (np + 15) / 16;
+    if (nsplit < 1) nsplit = 1;
+    const int per_split = (np + nsplit - 1) / nsplit, share_split = (nshare + nsplit - 1) / nsplit;
+    const size_t sz_part = (size_t)nshare * 256 * 8, sz_piece = (size_t)np * CG * 8, sz_small = ((size_t)2 * nchunk + 4) * CG * 8,
+                 sz_red = (size_t)nsplit * 256 * 8, sz_redc = (size_t)nsplit * CG * CG * 8;
+    const size_t o_pcnt = 0, o_ptile = o_pcnt + (size_t)np * 4, sz_plan = o_ptile + (size_t)np;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    HIP_TRY(K.all.alloc(up(sz_part) + 2 * up(sz_piece) + up(sz_small) + up(sz_red) + up(sz_redc) + up(sz_plan)));
+    char *cursor = K.all.as<char>();
+    auto carve = [&](size_t bytes) { char *r = cursor; cursor += up(bytes); return r; };
+    K.part = (double *)carve(sz_part);
+    K.pd = (double *)carve(sz_piece);
+    K.pe = (double *)carve(sz_piece);
+    K.small = (double *)carve(sz_small);
+    K.red = (double *)carve(sz_red);
+    K.redc = (double *)carve(sz_redc);
+    char *pb = carve(sz_plan);
+    // columns >= p of a piece's record are never written by the walk; the chain kernels read all CG
+    HIP_TRY(hipMemsetAsync(K.pd, 0, 2 * up(sz_piece), s));
+    hipLaunchKernelGGL(lane_fill_pieces_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, F.L, (int *)(pb + o_pcnt),
+                       (unsigned char *)(pb + o_ptile));
+    HIP_TRY(hipGetLastError());
+    K.nshare = nshare;
+    K.np = np;
+    K.nchunk = nchunk;
+    K.nsplit = nsplit;
+    K.per_split = per_split;
+    K.share_split = share_split;
+    K.dpcnt = (int *)(pb + o_pcnt);
+    timing_reset("olbm_few_kernel");
+    timing_begin(s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nshare), dim3(64), 0, s, x, n, p, len, F, K.part, K.pd, K.pe);
+    timing_end(s);
+    HIP_TRY(hipGetLastError());
+    double *csum = K.small, *tsum = csum + (size_t)nchunk * CG;
+    if (int rc = olbm_chain_pieces(K.pe, (const unsigned char *)(pb + o_ptile), np, CG, csum, tsum, s)) return rc;
+    return finish_few<CG>(x, n, p, len, dcentre, dmean_out, ddelta, dvar, dc, K);
+}
+
 }  // namespace
 
 // Host-only check of the plan (no GPU call; tests/test_host_cpu.py), as mcmchip_olbm_comb_plan_check: the arrays are made
@@ -527,21 +899,35 @@ extern "C" int mcmchip_olbm_lane_plan_check(int64_t nwin, int64_t len, int64_t g
     return bad;
 }
 
+extern "C" int mcmchip_olbm_few_plan_check(int64_t nwin, int64_t len, int64_t groups, int32_t sub, int32_t *npieces,
+                                           int64_t *min_steps, int64_t *max_steps)
+{
+    if (nwin < 1 || len < 1 || groups < 1 || (sub != 2 && sub != 4)) return -1;
+    CombPlan pl;
+    few_plan_arrays(make_few_plan((long)nwin, (long)len, (long)groups, sub), pl);
+    long lo = 0, hi = 0;
+    const int bad = olbm_plan_violations(pl, (long)nwin, (long)len, 4, npieces, &lo, &hi);
+    if (min_steps) *min_steps = lo;
+    if (max_steps) *max_steps = hi;
+    return bad;
+}
+
 bool olbm_lane_applies(long n, int p, long len)
 {
     static const char *env = getenv("MCMCHIP_OLBM_LANE");
     if (env && env[0] == '0') return false;
-    // Measured at n = 1e8, len = 1e4 (ms per call, this kernel / what served before): p = 4: 1.8 / 2.3 (olbm_small), p = 5: 1.9 / 3.0,
-    // p = 8: 2.1 / 6.0, p = 9: 2.1 / 14.4 (olbm_mfma_kernel), p = 16: 2.7 / 14.5, p = 32: 5.8 / 15.6, p = 64: 15.4 / 22.4, p = 65: 24.2 / 44.7
-    // (olbm_comb_kernel), p = 128: 41.4 / 46.2, p = 129: 64.7 / 111.5, p = 192: 80.3 / 112.0; p <= 3 stays with olbm_small
-    // (p = 3: 1.8 / 1.6), and so does a series of fewer than 1e6 rows of few columns (n = 1e5, p = 8: 0.27 / 0.11 ms per call).
+    // Measured at n = 1e8, len = 1e4 (ms per call, this file / what served before): p = 3: 1.3 / 1.45 (olbm_small), p = 4: 1.3 / 2.3,
+    // p = 5: 1.7 / 3.0, p = 8: 1.8 / 6.0 (olbm_few_kernel); p = 9: 2.1 / 14.4 (olbm_mfma_kernel), p = 16: 2.7 / 14.5, p = 32: 5.8 / 15.6,
+    // p = 64: 15.4 / 22.4, p = 65: 24.2 / 44.7 (olbm_comb_kernel), p = 128: 41.4 / 46.2, p = 129: 64.7 / 111.5, p = 192: 80.3 / 112.0;
+    // p <= 2 stays with olbm_small (p = 2: 1.34 / 1.18), and so do few columns of a shorter series (n p < 4e7: n = 1e7, len = 1e3:
+    // p = 3: 0.52 / 0.39, p = 4: 0.55 / 0.55, p = 8: 0.45 / 0.88; n = 2e6: p = 4: 0.43 / 0.35, p = 8: 0.38 / 0.45).
     // MCMCHIP_OLBM_LANE=<min len> lowers the window threshold and takes every p <= 192 (tests/fuzz_olbm_lane.py).
     long min_len = 256;
-    int min_p = 4;
-    long min_n_few = 1000000;
-    if (env && atol(env) > 1) { min_len = atol(env); min_p = 1; min_n_few = 0; }
+    int min_p = 3;
+    long min_np_few = 40000000;
+    if (env && atol(env) > 1) { min_len = atol(env); min_p = 1; min_np_few = 0; }
     const long nwin = n - len + 1;
-    if (p <= 8 && n < min_n_few) return false;
+    if (p <= 8 && n * p < min_np_few) return false;
     static const int max_p = getenv("MCMCHIP_OLBM_LANE_MAXP") ? atoi(getenv("MCMCHIP_OLBM_LANE_MAXP")) : OL_LANE_MAX_P;
     return p >= min_p && p <= max_p && len >= min_len && nwin >= 4 * len;
 }
@@ -561,7 +947,12 @@ int run_olbm_lane(const double *x, long n, int p, long len, double *mean, double
     double *mean_out = one_pass ? dmean : nullptr;
     const int nb = (p + 15) / 16;
     static const int tt = getenv("MCMCHIP_OLBM_LANE_T") ? atoi(getenv("MCMCHIP_OLBM_LANE_T")) : 16;
+    static const bool few = !(getenv("MCMCHIP_OLBM_FEW") && getenv("MCMCHIP_OLBM_FEW")[0] == '0');
     auto walk = [&](bool first_time, const double *cen, double *mo, double *dl) {
+        if (few && p <= 4)
+            return first_time ? launch_few<4>(x, n, p, len, cen, mo, dl, dvar, dc, K) : finish_few<4>(x, n, p, len, cen, mo, dl, dvar, dc, K);
+        if (few && p <= 8)
+            return first_time ? launch_few<8>(x, n, p, len, cen, mo, dl, dvar, dc, K) : finish_few<8>(x, n, p, len, cen, mo, dl, dvar, dc, K);
 #define OL_CASE_T(NBV, TV)                                                                                   \
     if (nb == NBV && (tt == TV || TV == 16))                                                                 \
         return first_time ? launch_lane<NBV, TV>(x, n, p, len, cen, mo, dl, dvar, dc, K)                     \

@@ -75,7 +75,7 @@ int olbm_chain_chunks(int npieces);
 int olbm_chain_pieces(double *pe, const unsigned char *ptile, int npieces, int PP, double *csum, double *tsum, hipStream_t s);
 int olbm_chain_means(const double *tsum, int nchunk, int PP, int p, const double *s0, const double *tail, const double *centre,
                      long n, long len, int want_mean, double *mean, double *delta, double *shift, hipStream_t s);
-// olbm_lane.hip: 4 <= p <= 192 columns, long windows: a wave walks four teeth, one lane per (tooth, column)
+// olbm_lane.hip: 3 <= p <= 192 columns, long windows: a wave walks four teeth, one lane per (tooth, column)
 bool olbm_lane_applies(long n, int p, long len);
 int run_olbm_lane(const double *x, long n, int p, long len, double *mean, double *var, int nocalc, DeviceCtx *dc);
 // olbm_small.hip: p <= 8 on the vector units

@@ -17,7 +17,7 @@ from mcmc_amd import api  # noqa: E402
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
-    p = int(rng.choice([1, 2, 7, 9, 15, 16, 17, 24, 31, 32, 33, 40, 48, 49, 63, 64, 65, 80, 81, 96, 100, 112, 113, 128, 129, 144, 150, 160, 161, 176, 177, 192]))
+    p = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 40, 48, 49, 63, 64, 65, 80, 81, 96, 100, 112, 113, 128, 129, 144, 150, 160, 161, 176, 177, 192]))
     n = int(rng.choice([257, 1000, 1025, 4099, 30000, 262144, 1_048_576, 1_300_001]))
     if n * p > 12_000_000:
         n = 12_000_000 // p
@@ -44,7 +44,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     st = np.sqrt(np.outer(np.diag(true), np.diag(true))) + 1e-300
     t_dev, t_orc = np.max(np.abs(got_d - true) / st), np.max(np.abs(ref - true) / st)
     sym = np.array_equal(got, got.T) and np.array_equal(got_d, got_d.T)
-    ok = sym and kn == "olbm_lane_kernel" and max(err_a, err_b) < (1e-10 if blen <= 10_000 and 4 * blen <= n else 1e-9) + 3 * t_orc and t_dev < max(1e-12 if 4 * blen <= n else 1e-10, 3 * t_orc)
+    ok = sym and kn == ("olbm_few_kernel" if p <= 8 else "olbm_lane_kernel") and max(err_a, err_b) < (1e-10 if blen <= 10_000 and 4 * blen <= n else 1e-9) + 3 * t_orc and t_dev < max(1e-12 if 4 * blen <= n else 1e-10, 3 * t_orc)
     bad += not ok
     print("n=%d p=%d len=%d  vs oracle %.1e / %.1e  vs 80-bit: device %.1e oracle %.1e  sym %s %s%s" % (n, p, blen, err_a, err_b, t_dev, t_orc, sym, kn, "" if ok else "  <<<<<<"), flush=True)
 print("bad", bad)

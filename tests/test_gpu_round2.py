@@ -870,9 +870,9 @@ def test_olbm_comb_route_vs_oracle(api, oracle_mod, n, p, blen):
 def _olbm_route(n, p, blen):
     """Which kernel diag.hip::run_olbm hands a shape to (olbm_small_applies / olbm_lane_applies / olbm_comb_applies)."""
     nwin = n - blen + 1
-    lane = 4 <= p <= 192 and blen >= 256 and nwin >= 4 * blen and (p > 8 or n >= 1_000_000)
-    if lane:
-        return "olbm_lane_kernel"        # a lane per (tooth, column), no scan (olbm_lane.hip)
+    lane = 3 <= p <= 192 and blen >= 256 and nwin >= 4 * blen and (p > 8 or n * p >= 40_000_000)
+    if lane:                             # a lane per (tooth, column), no scan (olbm_lane.hip); p <= 8: 2 or 4 units side by side
+        return "olbm_few_kernel" if p <= 8 else "olbm_lane_kernel"
     if p <= 8:
         return "olbm_small_kernel"       # the streaming kernel on the vector units (olbm_small.hip)
     if p > 64 and p <= 256 and blen >= 1024 and nwin >= 2 * blen:
@@ -881,11 +881,13 @@ def _olbm_route(n, p, blen):
 
 
 @pytest.mark.parametrize("n,p,blen", [(300_000, 9, 256), (200_000, 16, 1000), (120_000, 31, 5000), (90_000, 48, 3001),
-                                       (2_100_000, 6, 4096), (64_000, 64, 12_800), (70_001, 33, 777), (2_000_003, 5, 400_000),
-                                       (40_000, 130, 1024), (30_000, 192, 700), (25_000, 100, 333), (20_000, 160, 2500),
-                                       (1_000_000, 4, 999)])
+                                       (64_000, 64, 12_800), (70_001, 33, 777), (40_000, 130, 1024), (30_000, 192, 700),
+                                       (25_000, 100, 333), (20_000, 160, 2500),
+                                       (5_000_001, 8, 2000), (10_000_000, 4, 2500), (13_400_000, 3, 700), (8_000_000, 5, 333),
+                                       (6_000_000, 7, 40_000)])
 def test_olbm_lane_route_vs_oracle(api, oracle_mod, n, p, blen):
-    """4 .. 192 columns (up to 8 only from 1e6 rows on) and windows of >= 256 rows take olbm_lane.hip: a wave walks four teeth one window length apart with
+    """3 .. 192 columns (up to 8 only from n p = 4e7 on, with 2 or 4 units of the plan side by side in an instruction:
+    olbm_few_kernel) and windows of >= 256 rows take olbm_lane.hip: a wave walks four teeth one window length apart with
     one lane per (tooth, column), window sums are running sums in registers (no scan), five rows feed four teeth, units of
     the sweep are dealt round-robin to the workgroups, pieces chained and rank-two terms added afterwards, exact means out
     of the chain.  Against the oracle at 1e-10 (1e-9 where olbm.c's own arithmetic is good for no more: windows beyond
@@ -904,7 +906,7 @@ def test_olbm_lane_route_vs_oracle(api, oracle_mod, n, p, blen):
     sc = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
     tol = 1e-10 if blen <= 10_000 and 4 * blen <= n else 1e-9
     got = api.olbm(x, blen)                          # means supplied
-    assert api.last_kernel_time()[0] == "olbm_lane_kernel" == _olbm_route(n, p, blen)
+    assert api.last_kernel_time()[0] == _olbm_route(n, p, blen) and _olbm_route(n, p, blen) in ("olbm_lane_kernel", "olbm_few_kernel")
     assert np.all(np.abs(got - ref) <= tol * sc)
     assert np.array_equal(got, got.T)
     got2 = api.olbm(x, blen, demean=False)           # means computed by the call
@@ -958,7 +960,7 @@ def test_olbm_lane_series_beyond_the_32_bit_offsets(api, oracle_mod):
     x += 2.5
     torch.cuda.synchronize()
     var, mean = api.olbm_device(x, blen)
-    assert api.last_kernel_time()[0] == "olbm_lane_kernel"
+    assert api.last_kernel_time()[0] == "olbm_few_kernel"      # p <= 8: two units of the plan side by side in an instruction
     # (the rank-two terms evaluate the expression of the ORDERED pair of columns, so that var is symmetric to the bit; two
     # equal columns therefore agree to rounding, not to the bit)
     sc = np.sqrt(np.outer(np.diag(var), np.diag(var)))

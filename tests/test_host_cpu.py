@@ -325,3 +325,28 @@ def test_olbm_lane_plan_covers_every_window_once():
         assert f(99_990_001, 10_000, groups, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0
         mean_steps = 99_990_001 / 16 / groups
         assert hi.value <= 1.10 * mean_steps + 8, (groups, hi.value, mean_steps)
+
+
+def test_olbm_few_plan_covers_every_window_once():
+    """The plan of olbm_few_kernel (p <= 8: 2 or 4 consecutive units of olbm_lane.hip's plan side by side in one instruction,
+    bundles dealt round-robin): every window in exactly one piece, pieces in time order without gaps.  No GPU call."""
+    import ctypes as C
+    from mcmc_amd import api
+    f = api.load_library().mcmchip_olbm_few_plan_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(6)
+    npieces, lo, hi = C.c_int32(), C.c_int64(), C.c_int64()
+    cases = [(99_990_001, 10_000, 4608, 4), (99_990_001, 10_000, 4608, 2), (17, 16, 256, 4), (1, 1, 1, 2), (33, 16, 3, 4),
+             (4097, 1024, 512, 2), (2_000_001, 1_000_000, 256, 4), (1_600_004, 400_000, 2304, 4), (51_201, 12_800, 512, 2)]
+    for _ in range(300):
+        ln = int(rng.choice([1, 2, 15, 16, 17, 31, 100, 256, 1024, 1027, 4096, 20_000]))
+        nwin = int(rng.integers(1, 60)) * ln + int(rng.integers(0, ln))
+        cases.append((max(nwin, 1), ln, int(rng.choice([1, 2, 7, 256, 1024, 4608])), int(rng.choice([2, 4]))))
+    for nwin, ln, groups, sub in cases:
+        assert f(nwin, ln, groups, sub, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0, (nwin, ln, groups, sub)
+        assert npieces.value >= -(-nwin // ln)
+    for sub in (2, 4):
+        assert f(99_990_001, 10_000, 4608, sub, C.byref(npieces), C.byref(lo), C.byref(hi)) == 0
+        mean_steps = 99_990_001 / 16 / 4608
+        assert hi.value <= 1.15 * mean_steps + 8 * sub, (sub, hi.value, mean_steps)
