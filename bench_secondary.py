@@ -131,6 +131,31 @@ def c5(api, torch, dev, n=100_000_256, p=256, blen=10_000):
                                  "x[t+2k+1])), i.e. half the reference's count, and computes lags speculatively"},
             "var_con_over_gamma0": [float(v) for v in (vc / g0)[[0, p // 2, p - 1]]],
             "theory_(1+rho)/(1-rho)": [(1 + r) / (1 - r) for r in (0.5, 0.5 + 0.49 * (p // 2) / max(p - 1, 1), 0.99)]}]
+    # the same series handed over as NOT centred: about a provisional centre in the same passes (mcmchip_initseq_uncentred),
+    # next to what that cost before (centre in place: a read pass and a read-write pass, then the call above)
+    n_u = np.zeros(p, dtype=np.int64)
+    g0u, vpu, vdu, vcu, mean_u = (np.empty(p) for _ in range(5))
+    secs_u = []
+    for rep in range(2):
+        t0 = time.perf_counter()
+        rc = L.mcmchip_initseq_uncentred(x.data_ptr(), n, p, 1, cap, n_u.ctypes.data, g0u.ctypes.data, Gp.ctypes.data,
+                                         Gd.ctypes.data, Gc.ctypes.data, vpu.ctypes.data, vdu.ctypes.data, vcu.ctypes.data,
+                                         mean_u.ctypes.data)
+        secs_u.append(time.perf_counter() - t0)
+        if rc:
+            raise RuntimeError(L.mcmchip_last_error().decode())
+    t0 = time.perf_counter()
+    rc = L.mcmchip_series_centre(x.data_ptr(), n, p, None)         # the series is centred already: this subtracts ~1e-17
+    centre_s = time.perf_counter() - t0
+    if rc:
+        raise RuntimeError(L.mcmchip_last_error().decode())
+    res.append({"workload": "C5: initseq of the same series handed over as not centred (mcmchip_initseq_uncentred: lag sums about a "
+                            "provisional centre, carried over to the mean on the host; the series is read once per round and not modified)",
+                "seconds": min(secs_u), "kernel": "autocov_kernel",
+                "before": {"centre_in_place_seconds": centre_s, "then_initseq_seconds": el, "total": centre_s + el},
+                "same_stopping_lags": bool(np.array_equal(n_u, n_out)),
+                "max_rel_diff_var_con": float(np.max(np.abs(vcu - vc) / np.abs(vc))),
+                "max_abs_mean": float(np.max(np.abs(mean_u)))})
     mean = np.zeros(p)
     var = np.empty((p, p))
     for nocalc in (0, 1):

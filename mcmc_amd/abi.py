@@ -153,6 +153,7 @@ EXPORTS = [
     "mcmchip_metrop_multi",
     "mcmchip_temper_multi",
     "mcmchip_initseq",
+    "mcmchip_initseq_uncentred",
     "mcmchip_olbm_comb_plan_check",
     "mcmchip_olbm_lane_plan_check",
     "mcmchip_olbm_few_plan_check",

@@ -64,6 +64,8 @@ def load_library():
     L.mcmchip_temper_multi.restype = C.c_int
     L.mcmchip_initseq.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64] + [C.c_void_p] * 8
     L.mcmchip_initseq.restype = C.c_int
+    L.mcmchip_initseq_uncentred.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64] + [C.c_void_p] * 9
+    L.mcmchip_initseq_uncentred.restype = C.c_int
     L.mcmchip_chain_summary.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
     L.mcmchip_chain_summary.restype = C.c_int
     L.mcmchip_chain_summary_combine.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -484,15 +486,15 @@ def initseq(x, centred=False):
     """initseq(x): R/initseq.R:1-5 -- x numeric, all finite; the series is centred here and the
     centred series goes to the native routine.  A 2-d x (len x ncol) is a batch of series and
     returns a list of results.
-    A DeviceSeries (upload_series) or a float64 CUDA tensor of shape (ncol, len) is taken as the native routine takes its
-    argument (initseq.c:7): centred already, which the caller states with centred = True; the device checks that it is
-    finite."""
+    A DeviceSeries (upload_series) or a float64 CUDA tensor of shape (ncol, len) is resident in HBM already and is not
+    modified: with centred = True it is taken as the native routine takes its argument (initseq.c:7), otherwise about its
+    column means in the same passes (mcmchip_initseq_uncentred: nothing is subtracted in place).  The device checks that it
+    is finite."""
+    about_mean = False
     if isinstance(x, DeviceSeries) or (hasattr(x, "data_ptr") and hasattr(x, "is_cuda")):
-        # resident in HBM already (a DeviceSeries, or a contiguous float64 CUDA tensor of shape (ncol, len))
-        if not centred:
-            raise ValueError("a series in HBM goes to the native routine as it is: centre it first and pass centred=True")
         single = False
         src = x
+        about_mean = not centred
     else:
         x = np.asarray(x)
         if not np.issubdtype(x.dtype, np.number):
@@ -501,12 +503,11 @@ def initseq(x, centred=False):
         single = x.ndim == 1
         xm = x[:, None] if single else x
         if x.nbytes >= _UPLOAD_MIN_BYTES:
-            # a large series: uploaded as it is, centred (and checked for non-finite values) on the device -- three
-            # passes over a GB-sized array on the host cost ten times the upload
+            # a large series: uploaded as it is, taken about its means (and checked for non-finite values) on the device --
+            # three passes over a GB-sized array on the host cost ten times the upload
             init()
             src = upload_series(xm)
-            if not centred:
-                src.centre()
+            about_mean = not centred
         else:
             if not np.all(np.isfinite(x)):
                 raise ValueError("all(is.finite(x)) is not TRUE")
@@ -519,9 +520,14 @@ def initseq(x, centred=False):
         n_out = np.zeros(ncol, dtype=np.int64)
         g0, vp, vd, vc = (np.empty(ncol) for _ in range(4))
         Gp, Gd, Gc = (np.empty((ncol, cap)) for _ in range(3))
-        rc = L.mcmchip_initseq(ptr, length, ncol, dp, cap, n_out.ctypes.data, g0.ctypes.data,
-                               Gp.ctypes.data, Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data,
-                               vd.ctypes.data, vc.ctypes.data)
+        if about_mean:
+            rc = L.mcmchip_initseq_uncentred(ptr, length, ncol, dp, cap, n_out.ctypes.data, g0.ctypes.data,
+                                             Gp.ctypes.data, Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data,
+                                             vd.ctypes.data, vc.ctypes.data, None)
+        else:
+            rc = L.mcmchip_initseq(ptr, length, ncol, dp, cap, n_out.ctypes.data, g0.ctypes.data,
+                                   Gp.ctypes.data, Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data,
+                                   vd.ctypes.data, vc.ctypes.data)
         if rc == abi.ECAP:
             cap = int(n_out.max())
             continue

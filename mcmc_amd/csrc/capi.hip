@@ -795,6 +795,26 @@ int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs,
                        Gamma_con, var_pos, var_dec, var_con, dc);
 }
 
+int mcmchip_initseq_uncentred(const double *x, int64_t len, int64_t ncol, int device_ptrs, int64_t cap,
+                              int64_t *n_out, double *gamma0, double *Gamma_pos, double *Gamma_dec,
+                              double *Gamma_con, double *var_pos, double *var_dec, double *var_con, double *mean)
+{
+    clear_error();
+    DeviceCtx *dc = cur_dev();
+    if (!dc) return MCMCHIP_EHIP;
+    if (!x) return set_error(MCMCHIP_EINVAL, "argument must be numeric");
+    if (len <= 0 || ncol <= 0 || cap <= 0 || !n_out || !gamma0 || !Gamma_pos || !Gamma_dec || !Gamma_con ||
+        !var_pos || !var_dec || !var_con)
+        return set_error(MCMCHIP_EINVAL, "bad argument to mcmchip_initseq_uncentred");
+    if (!device_ptrs)
+        for (size_t i = 0; i < (size_t)len * ncol; i++)
+            if (!isfinite(x[i])) return set_error(MCMCHIP_EINVAL, "all elements of argument must be finite");
+    InBuf in;
+    HIP_TRY(in.set(x, (size_t)len * ncol * 8, device_ptrs, dc->stream));
+    return run_initseq(in.as<double>(), len, ncol, cap, (long *)n_out, gamma0, Gamma_pos, Gamma_dec,
+                       Gamma_con, var_pos, var_dec, var_con, dc, true, mean);
+}
+
 int mcmchip_lagsums(const double *x, int64_t len, int64_t ncol, int64_t nlags, int device_ptrs, double *sums)
 {
     clear_error();

@@ -36,6 +36,33 @@ __global__ __launch_bounds__(256) void autocov_reduce_kernel(const double *__res
     }
 }
 
+// The provisional centre of mcmchip_initseq_uncentred: the mean of 64 runs of 1024 rows spread evenly over the column (of
+// the whole column up to 65 536 rows).  Any value would do -- the sums about the mean follow exactly (centre_correction)
+// -- but the nearer the centre lies to the mean, the fewer digits the correction cancels: a sample over the WHOLE
+// length, so that a drifting start (burn-in) does not decide it.
+__global__ __launch_bounds__(256) void sample_centre_kernel(const double *__restrict__ x, long len, double *__restrict__ centre)
+{
+    __shared__ double red[4];
+    constexpr long SEG = 1024, NSEG = 64;
+    const double *xc = x + (size_t)blockIdx.x * len;
+    double s = 0.0;
+    long cnt = len;
+    if (len <= SEG * NSEG) {
+        for (long t = threadIdx.x; t < len; t += 256) s += xc[t];
+    } else {
+        cnt = SEG * NSEG;
+        for (long j = 0; j < NSEG; j++) {
+            const long start = j * (len - SEG) / (NSEG - 1);
+#pragma unroll
+            for (long t = threadIdx.x; t < SEG; t += 256) s += xc[start + t];
+        }
+    }
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) centre[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) / (double)cnt;
+}
+
 // Host post-processing of one column's Gamma sequence (a few hundred numbers).  What initseq.c:49-105 returns:
 //   Gamma.pos  the sequence as computed (truncated at the first negative term, which is stored as 0),
 //   Gamma.dec  its greatest non-increasing minorant = running minimum,
@@ -186,8 +213,9 @@ struct LagBuffers {
 };
 
 // runs the round over time blocks [0, nblk_run) and leaves nunit * IS_B sums in `host`
+// centre != nullptr: the lag pairs about the provisional centres (device, one per column)
 int run_lag_round(const double *x, long len, const TimeGrid &tg, long nblk_run, const LagRound &w, LagBuffers &B,
-                  std::vector<double> &host, DeviceCtx *dc)
+                  std::vector<double> &host, DeviceCtx *dc, const double *centre = nullptr)
 {
     hipStream_t s = dc->stream;
     const size_t nunit = (size_t)w.nunit;
@@ -233,13 +261,23 @@ int run_lag_round(const double *x, long len, const TimeGrid &tg, long nblk_run, 
         timing_begin(s);
         switch (kVariants[v].fam) {
         case FAM_FIRST:
+            if (centre) {
+                rc = launch_autocov_first_ca(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>(), centre);
+                if (rc < 0) rc = launch_autocov_first_cb(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>(), centre);
+                break;
+            }
             rc = launch_autocov_first_a(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
             if (rc < 0) rc = launch_autocov_first_b(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
             break;
         case FAM_CONT:
+            if (centre) {
+                rc = launch_autocov_cont_c(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>(), centre);
+                break;
+            }
             rc = launch_autocov_cont(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
             break;
         default:
+            if (centre) return set_error(MCMCHIP_EINVAL, "initseq: single lags are not taken about a centre");
             rc = launch_autocov_raw(nacc, grid, s, x, len, dcol + offs[v], dl + offs[v], dunit + offs[v], nblk_run, (int)tg.tpb, B.partial.as<double>());
         }
         timing_end(s);
@@ -276,13 +314,78 @@ double predict_pairs(const double *G, long m, long len)
     const double decay = std::log(G[0] / G[j]) / (double)j;        // per lag pair
     return 0.5 * std::log((double)len) / decay;
 }
+
+// From sums about a provisional centre to sums about the mean (mcmchip_initseq_uncentred).  With z[t] = x[t] - centre,
+// S = sum z, delta = S / len (so mean = centre + delta) and w[t] = z[t] - delta the series initseq.c is handed:
+//     sum_{t < len-k} w[t] w[t+k] = sum_{t < len-k} z[t] z[t+k] - delta (2 S - H_k - T_k) + (len - k) delta^2
+//                                 = sum_{t < len-k} z[t] z[t+k] - (len + k) delta^2 + delta (H_k + T_k),
+// H_k (T_k) the sum of the first (last) k values of z.  This holds H_k + T_k per column for k <= K, from the first and last
+// K rows of the series copied to the host (two strided copies for all columns; a column that goes beyond K lags -- rare:
+// K starts at 2048 -- has its edges fetched again, alone).
+struct EdgeSums {
+    long K = 0;
+    std::vector<std::vector<double>> ht;          // [column][k], k = 0 .. K (of the columns asked for last)
+    std::vector<double> head, tail;
+    int ensure(const double *x, long len, long ncol, const std::vector<int> &cols, long need, const std::vector<double> &cen, hipStream_t s)
+    {
+        if (need > len) need = len;
+        if (need <= K) return MCMCHIP_OK;
+        const bool all = K == 0;
+        // first for all columns at once: at most 2048 rows, and at most 2 x 256 MB of host memory however many columns
+        long k = K == 0 ? std::max(64L, std::min(2048L, (32L << 20) / ncol)) : 2 * K;
+        if (k < need) k = need;
+        if (k > len) k = len;
+        K = k;
+        if (all) {
+            ht.assign((size_t)ncol, std::vector<double>());
+            head.resize((size_t)ncol * K);
+            tail.resize((size_t)ncol * K);
+            HIP_TRY(hipMemcpy2DAsync(head.data(), (size_t)K * 8, x, (size_t)len * 8, (size_t)K * 8, (size_t)ncol, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpy2DAsync(tail.data(), (size_t)K * 8, x + (len - K), (size_t)len * 8, (size_t)K * 8, (size_t)ncol, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (long c = 0; c < ncol; c++) fill(c, head.data() + (size_t)c * K, tail.data() + (size_t)c * K, cen[(size_t)c]);
+        } else {
+            head.resize((size_t)K);
+            tail.resize((size_t)K);
+            for (int c : cols) {
+                HIP_TRY(hipMemcpyAsync(head.data(), x + (size_t)c * len, (size_t)K * 8, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipMemcpyAsync(tail.data(), x + (size_t)c * len + (len - K), (size_t)K * 8, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                fill(c, head.data(), tail.data(), cen[(size_t)c]);
+            }
+        }
+        return MCMCHIP_OK;
+    }
+    void fill(long c, const double *h, const double *t, double centre)
+    {
+        std::vector<double> &v = ht[(size_t)c];
+        v.resize((size_t)K + 1);
+        double hs = 0.0, ts = 0.0;
+        v[0] = 0.0;
+        for (long k = 1; k <= K; k++) {
+            hs += h[k - 1] - centre;              // the kernel's z, rounded as there
+            ts += t[K - k] - centre;
+            v[(size_t)k] = hs + ts;
+        }
+    }
+    // what to add to the kernel's sum for lag pair i (lags 2i and 2i + 1)
+    double pair_correction(long c, long i, long len, double delta) const
+    {
+        const std::vector<double> &v = ht[(size_t)c];
+        const long k = 2 * i;
+        return delta * (v[(size_t)k] + v[(size_t)k + 1]) - ((double)(len + k) + (double)(len + k + 1)) * delta * delta;
+    }
+};
 }  // namespace
 
 #define IS_MAX_UNITS_PER_LAUNCH 32      // at most 1024 new lags per column and round
 #define IS_PILOT_POSITIONS (1L << 21)   // pilot pass: at most the first 2M positions of every column
 
+// about_mean: x is taken about its column means (R/initseq.R:3) without being modified or read more than once per round:
+// lag sums about a provisional centre, corrected on the host (EdgeSums); the means go to mean_out (host, or NULL)
 int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0, double *Gpos,
-                double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon, DeviceCtx *dc)
+                double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon, DeviceCtx *dc, bool about_mean,
+                double *mean_out)
 {
     const long half = len / 2;
     // tiles start at position -IS_PAD (zero padded), so every result row of an MFMA sees every base position
@@ -309,6 +412,21 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
     for (long c = 0; c < ncol; c++) active.push_back((int)c);
     std::vector<double> host;
     timing_reset("autocov_kernel");
+    DevBuf dcentre;
+    std::vector<double> cen, delta;                      // provisional centre; mean - centre once a full pass has summed the column
+    EdgeSums edges;
+    const double *centre = nullptr;
+    if (about_mean) {
+        if (ncol > 0x7fffffffL) return set_error(MCMCHIP_EINVAL, "too many columns");
+        HIP_TRY(dcentre.alloc((size_t)ncol * 8));
+        hipLaunchKernelGGL(sample_centre_kernel, dim3((unsigned)ncol), dim3(256), 0, dc->stream, x, len, dcentre.as<double>());
+        HIP_TRY(hipGetLastError());
+        cen.resize((size_t)ncol);
+        delta.assign((size_t)ncol, 0.0);
+        HIP_TRY(hipMemcpyAsync(cen.data(), dcentre.p, (size_t)ncol * 8, hipMemcpyDeviceToHost, dc->stream));
+        HIP_TRY(hipStreamSynchronize(dc->stream));
+        centre = dcentre.as<double>();
+    }
     if (half == 0) active.clear();
     long npilot = 0;                                     // time blocks of the pilot: 1/64 of a series of 1M positions and more
     if (len >= (1L << 20)) {
@@ -318,13 +436,23 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
     if (npilot > 0 && !active.empty()) {
         work.clear();
         unit0.assign(active.size(), 0);
+        ssq_at.assign(active.size(), -1);
         for (size_t a = 0; a < active.size(); a++) {
             long got;
-            unit0[a] = work.add(active[a], 0, 2, true, &got);
+            unit0[a] = work.add(active[a], 0, 2, true, &got, &ssq_at[a]);
         }
-        if (int rc = run_lag_round(x, len, tg, npilot, work, bufs, host, dc)) return rc;
-        for (size_t a = 0; a < active.size(); a++)
-            guess[(size_t)active[a]] = predict_pairs(host.data() + (size_t)unit0[a] * IS_B, 2 * PU, len);
+        if (int rc = run_lag_round(x, len, tg, npilot, work, bufs, host, dc, centre)) return rc;
+        for (size_t a = 0; a < active.size(); a++) {
+            double *g = host.data() + (size_t)unit0[a] * IS_B;
+            if (about_mean && ssq_at[a] >= 0) {
+                // about the pilot's own mean, near enough for a prediction: every sum holds two lag products over ~np positions
+                long np = npilot * tg.span - IS_PAD;
+                if (np > len) np = len;
+                const double sp = host[(size_t)ssq_at[a] * IS_B + 1];
+                for (int q = 0; q < 2 * PU; q++) g[q] -= 2.0 * sp * sp / (double)np;
+            }
+            guess[(size_t)active[a]] = predict_pairs(g, 2 * PU, len);
+        }
         if (trace) fprintf(stderr, "[initseq] pilot: %zu columns x 64 lags over %ld of %ld time blocks\n", active.size(), npilot, nblk);
     }
     while (!active.empty()) {
@@ -376,7 +504,12 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
             fprintf(stderr, "\n");
         }
         const auto t_round = std::chrono::steady_clock::now();
-        if (int rc = run_lag_round(x, len, tg, nblk, work, bufs, host, dc)) return rc;
+        if (int rc = run_lag_round(x, len, tg, nblk, work, bufs, host, dc, centre)) return rc;
+        if (about_mean) {
+            long need = 0;
+            for (size_t a = 0; a < active.size(); a++) need = std::max(need, 2 * (have[(size_t)active[a]] + units[a] * PU));
+            if (int rc = edges.ensure(x, len, ncol, active, need, cen, dc->stream)) return rc;
+        }
         if (trace) fprintf(stderr, "[initseq] round took %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count());
         std::vector<int> next;
         for (size_t a = 0; a < active.size(); a++) {
@@ -386,7 +519,13 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
             const long pair_first = have[(size_t)c];
             bool fin = false;
             if (ssq_at[a] >= 0) {
-                const double gam0 = host[(size_t)ssq_at[a] * IS_B] / len;            // initseq.c:30 at lag 0
+                double ssq = host[(size_t)ssq_at[a] * IS_B];
+                if (about_mean) {
+                    const double S = host[(size_t)ssq_at[a] * IS_B + 1];              // sum of x - centre
+                    delta[(size_t)c] = S / (double)len;
+                    ssq -= S * delta[(size_t)c];                                      // sum z^2 - len delta^2
+                }
+                const double gam0 = ssq / len;                                        // initseq.c:30 at lag 0
                 g0[(size_t)c] = gam0;
                 // the lag-0 sum of squares is finite iff every element is (short of overflow): this is where a
                 // series handed over as a device pointer gets the reference's finiteness check (initseq.c:15)
@@ -400,7 +539,7 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
             for (long q = 0; q < nb * PU && !fin; q++) {
                 const long i = pair_first + q;
                 if (i >= half) { done[(size_t)c] = half; fin = true; break; }
-                const double G = g[q] / len;                                          // gam1 + gam2, initseq.c:30,39,41
+                const double G = (about_mean ? g[q] + edges.pair_correction(c, i, len, delta[(size_t)c]) : g[q]) / len;   // gam1 + gam2, initseq.c:30,39,41
                 if (G < 0.0) {                                                    // initseq.c:42-46
                     Gam[(size_t)c].push_back(0.0);
                     done[(size_t)c] = i + 1;
@@ -423,6 +562,7 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
         long m = half == 0 ? 0 : done[(size_t)c];
         n_out[c] = m;
         gamma0[c] = g0[(size_t)c];
+        if (about_mean && mean_out) mean_out[c] = cen[(size_t)c] + delta[(size_t)c];
         if (m > cap) { overflow = true; continue; }
         gamma_sequences(Gam[(size_t)c].data(), m, g0[(size_t)c],
                         GammaOut{Gpos + (size_t)c * cap, Gdec + (size_t)c * cap, Gcon + (size_t)c * cap, vpos + c, vdec + c, vcon + c});

@@ -196,11 +196,19 @@ template <int NACC, int J0 = 0> __device__ __forceinline__ void autocov_pieces(u
 // item = (column cols[], first lag lag_of[] (FIRST: 0), NACC units from unit_of[] on) on grid.x, time block on grid.y.
 // partial[(unit * nblk + block) * 16 + e]: the block's share of sum_t x[t] y[t + lag0 + 32 J + 2 e], J the unit within
 // the item; FIRST && PAIR: one more unit, NACC, whose entry 0 is the block's share of sum_t x[t]^2.
-template <int NACC, bool FIRST, bool PAIR>
+//
+// CENTRE (round 3; mcmchip_initseq_uncentred): the series is taken about a provisional centre per column, z[t] = x[t] -
+// centre[col], subtracted while a tile goes from registers to LDS (the zeros before element 0 and past the end stay zeros:
+// the first and the last tiles of a series take a path with a range test per element, the tiles between them one without),
+// and entry 1 of the sum-of-squares unit carries the block's share of sum_t z[t].  What the sums about the MEAN are follows
+// on the host (initseq.hip, centre_correction): the series is read once, not three times (mean pass, subtract in place).
+template <int NACC, bool FIRST, bool PAIR, bool CENTRE = false>
 __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autocov_kernel(
     const double *__restrict__ x, long len, const int *__restrict__ cols, const long *__restrict__ lag_of,
-    const int *__restrict__ unit_of, long nblk, int tiles_per_block, double *__restrict__ partial)
+    const int *__restrict__ unit_of, long nblk, int tiles_per_block, double *__restrict__ partial,
+    const double *__restrict__ centre)
 {
+    static_assert(!CENTRE || PAIR, "the provisional centre serves initseq's lag pairs");
     using S = AcShape<NACC, FIRST, PAIR>;
     constexpr int SA = S::SA, SY = S::SY, NREG = S::NREG, IMG = S::IMG;
     extern __shared__ double ac_lds[];                    // [2][IMG] tile images; the cross-wave reduction reuses them
@@ -211,7 +219,9 @@ __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autoco
     double acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; j++) acc[j] = 0.0;
-    double ssq = 0.0;
+    double ssq = 0.0, ssum = 0.0;
+    double cen = 0.0;
+    if constexpr (CENTRE) cen = centre[col];
     const int q = lane & 3, blk = (lane >> 2) & 3, k = lane >> 4;
     const int offA = 8 * q + blk + 4 * k, offB = blk + 4 * k + 2 * q + 24;
     const unsigned lane_off = (unsigned)t * 8u;
@@ -266,9 +276,44 @@ __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autoco
             if constexpr (PAIR) fetch_seg_guarded(r + SA + 1, a + lag0, SY, 2, 1);
         }
     };
-    auto store = [&](const double(&r)[NREG], double *P) __attribute__((always_inline)) {
+    // a = the series position of the tile's element 0 (used by CENTRE only)
+    auto store = [&](const double(&r)[NREG], double *P, long a) __attribute__((always_inline)) {
         constexpr int YS = PAIR ? 2 : 1;
         constexpr int Y0 = FIRST ? 0 : SA;
+        if constexpr (CENTRE) {
+            // registers hold x (0 outside the series, and all of a tile past the block: `fetch`); in range -> x - cen
+            const bool live = a < stop;
+            const long ya = FIRST ? a : a + lag0;              // position of the y image's (second operand's) element 0
+            // in-range tile indices [lo, hi) of the x image's and of the y image's loads (scalars; a tile has < 2^13 elements)
+            auto clip = [](long v) __attribute__((always_inline)) { return (int)(v < 0 ? 0 : (v > (1L << 20) ? (1L << 20) : v)); };
+            const int lox = clip(-a), hix = live ? clip(len - a) : 0, loy = clip(-ya), hiy = live ? clip(len - ya) : 0;
+            auto body = [&](auto inner_c) __attribute__((always_inline)) {
+                constexpr bool INNER = inner_c;
+                // element t + e0 of an image: t against scalars
+                auto zx = [&](double v, int e0) __attribute__((always_inline)) { return (INNER || (t >= lox - e0 && t < hix - e0)) ? v - cen : 0.0; };
+                auto zy = [&](double v, int e0) __attribute__((always_inline)) { return (INNER || (t >= loy - e0 && t < hiy - e0)) ? v - cen : 0.0; };
+                if constexpr (!FIRST) {
+#pragma unroll
+                    for (int i = 0; i < SA; i++) P[t + 256 * i] = zx(r[i], 256 * i);
+                }
+#pragma unroll
+                for (int i = 0; i < SY; i++) {
+                    const double v0 = zy(r[Y0 + 2 * i], 256 * i), v1 = zy(r[Y0 + 2 * i + 1], 256 * i + 1);
+                    if constexpr (FIRST) {
+                        if (i < SA) P[t + 256 * i] = v0;
+                        if (i < IS_TILE / 256) {                // each position once
+                            ssq = __builtin_fma(v0, v0, ssq);
+                            ssum += v0;
+                        }
+                    }
+                    P[SA * 256 + t + 256 * i] = v0 + v1;
+                }
+            };
+            // every element the tile's loads touch lies inside the series (uniform over the workgroup)
+            if (lox == 0 && loy == 0 && hiy >= SY * 256 + 1 && hix >= SA * 256) body(std::true_type{});
+            else body(std::false_type{});
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < SA; i++) P[t + 256 * i] = r[FIRST ? YS * i : i];
 #pragma unroll
@@ -296,12 +341,12 @@ __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autoco
     double r[DEPTH][NREG];
     if constexpr (S::NBUF == 2) {
         fetch_first_tile(r[0], first);
-        store(r[0], ac_lds);
+        store(r[0], ac_lds, first);
         static_for<DEPTH>([&](auto d) __attribute__((always_inline)) { fetch(r[(d + 1) % DEPTH], first + (long)(d + 1) * IS_TILE); });
         lds_barrier();
         auto phase = [&](auto p, long tile) __attribute__((always_inline)) {   // tile + p: buffer p & 1; stages tile + p + 1, fetches tile + p + 1 + DEPTH
             constexpr int P = p, NEXT = (P + 1) % DEPTH;
-            store(r[NEXT], ac_lds + ((P + 1) & 1) * IMG);
+            store(r[NEXT], ac_lds + ((P + 1) & 1) * IMG, first + (tile + P + 1) * IS_TILE);
             fetch(r[NEXT], first + (tile + P + 1 + DEPTH) * IS_TILE);
             __builtin_amdgcn_sched_barrier(0);             // the loads go out before the MFMAs, not after them
             multiply(ac_lds + (P & 1) * IMG);
@@ -322,7 +367,7 @@ __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autoco
         auto phase = [&](auto p, long tile) __attribute__((always_inline)) {
             constexpr int P = p % DEPTH;
             lds_barrier();                                 // everyone has read the previous tile
-            store(r[P], ac_lds);
+            store(r[P], ac_lds, first + (tile + p) * IS_TILE);
             fetch(r[P], first + (tile + p + DEPTH) * IS_TILE);
             lds_barrier();
             multiply(ac_lds);
@@ -348,7 +393,9 @@ __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autoco
     if constexpr (FIRST && PAIR) {
         // store() squared every tile it staged: the ones past the block are zeros
         for (int m = 32; m > 0; m >>= 1) ssq += __shfl_xor(ssq, m, 64);
-        if (lane < 16) red[wave][16 * NACC + lane] = lane == 0 ? ssq : 0.0;
+        if constexpr (CENTRE)
+            for (int m = 32; m > 0; m >>= 1) ssum += __shfl_xor(ssum, m, 64);
+        if (lane < 16) red[wave][16 * NACC + lane] = lane == 0 ? ssq : (lane == 1 ? ssum : 0.0);
     }
     __syncthreads();
     constexpr int NOUT = 16 * NACC + (FIRST && PAIR ? 16 : 0);
@@ -360,16 +407,16 @@ __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autoco
 }
 
 // launches one variant; LDS = two buffers of an x and a y image (the cross-wave reduction reuses them at the end)
-template <int NACC, bool FIRST, bool PAIR>
+template <int NACC, bool FIRST, bool PAIR, bool CENTRE = false>
 int launch_autocov(dim3 grid, hipStream_t s, const double *x, long len, const int *pc, const long *pl, const int *pu,
-                   long nblk, int tiles_per_block, double *pp)
+                   long nblk, int tiles_per_block, double *pp, const double *centre = nullptr)
 {
     using S = AcShape<NACC, FIRST, PAIR>;
     const size_t lds = (size_t)S::NBUF * S::IMG * 8;
-    auto kern = autocov_kernel<NACC, FIRST, PAIR>;
+    auto kern = autocov_kernel<NACC, FIRST, PAIR, CENTRE>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, len, pc, pl, pu, nblk, tiles_per_block, pp);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, len, pc, pl, pu, nblk, tiles_per_block, pp, centre);
     return MCMCHIP_OK;
 }
 
@@ -380,3 +427,8 @@ int launch_autocov_first_a(AUTOCOV_LAUNCH_ARGS);      // pairs, lag 0 on
 int launch_autocov_first_b(AUTOCOV_LAUNCH_ARGS);
 int launch_autocov_cont(AUTOCOV_LAUNCH_ARGS);         // pairs, continuation
 int launch_autocov_raw(AUTOCOV_LAUNCH_ARGS);          // single lags of one parity (mcmchip_lagsums)
+// ... about a provisional centre per column (mcmchip_initseq_uncentred)
+#define AUTOCOV_CENTRE_ARGS AUTOCOV_LAUNCH_ARGS, const double *centre
+int launch_autocov_first_ca(AUTOCOV_CENTRE_ARGS);
+int launch_autocov_first_cb(AUTOCOV_CENTRE_ARGS);
+int launch_autocov_cont_c(AUTOCOV_CENTRE_ARGS);

@@ -102,7 +102,7 @@ int device_validate(DeviceCtx *dc, const double *v, long n, long stride, int k, 
 // diag.hip
 int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, double *gamma0,
                 double *Gpos, double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon,
-                DeviceCtx *dc);
+                DeviceCtx *dc, bool about_mean = false, double *mean_out = nullptr);
 int run_lagsums(const double *x, long len, long ncol, long nlags, double *sums, DeviceCtx *dc);
 int run_initseq_from_lagsums(const double *sums, long len, long ncol, long nlags, long cap, long *n_out, double *gamma0,
                              double *Gpos, double *Gdec, double *Gcon, double *vpos, double *vdec, double *vcon);

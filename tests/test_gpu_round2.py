@@ -215,8 +215,11 @@ def test_series_upload_and_device_transpose(api, oracle_mod, monkeypatch):
         for ca, cb in zip(ra, rb):
             for key in ca:
                 assert np.array_equal(ca[key], cb[key])
-        with pytest.raises(ValueError, match="centred=True"):
-            api.initseq(ds)
+        # not declared centred: taken about its means in the same passes (mcmchip_initseq_uncentred); here they are ~0
+        for ca, cu in zip(ra, api.initseq(ds)):
+            assert len(ca["Gamma.pos"]) == len(cu["Gamma.pos"])
+            for key in ca:
+                assert np.max(np.abs(np.asarray(ca[key]) - np.asarray(cu[key]))) <= 1e-10 * np.max(np.abs(ca[key]))
     # a C-ordered array above the threshold goes through the upload by itself: same bits as the in-place column-major call
     n, p = 300_000, 7
     x = rng.standard_normal((n, p)).cumsum(axis=0) * 1e-3 + rng.standard_normal((n, p))
@@ -766,6 +769,108 @@ def test_temper_index_and_moment_outfuns(api, oracle_mod, parallel, outfun):
 
 
 # ----------------------------------------------------------------------------- multi-GPU drivers on device-resident data
+INITSEQ_KEYS = ("gamma0", "Gamma.pos", "Gamma.dec", "Gamma.con", "var.pos", "var.dec", "var.con")
+
+
+def _initseq_uncentred_raw(api, ptr, n, p, device_ptrs, cap=8192):
+    """mcmchip_initseq_uncentred through the C-ABI: (rc, n_out, gamma0, Gamma.pos, Gamma.dec, Gamma.con, var.*, mean)"""
+    L = api.load_library()
+    n_out = np.zeros(p, dtype=np.int64)
+    g0, vp, vd, vc, mean = (np.empty(p) for _ in range(5))
+    Gp, Gd, Gc = (np.empty((p, cap)) for _ in range(3))
+    rc = L.mcmchip_initseq_uncentred(ptr, n, p, device_ptrs, cap, n_out.ctypes.data, g0.ctypes.data, Gp.ctypes.data,
+                                     Gd.ctypes.data, Gc.ctypes.data, vp.ctypes.data, vd.ctypes.data, vc.ctypes.data,
+                                     mean.ctypes.data)
+    return rc, n_out, g0, Gp, Gd, Gc, vp, vd, vc, mean
+
+
+@pytest.mark.parametrize("n,rhos,kind", [
+    (1000, (0.3, -0.4, 0.9), "offset"),
+    (2015, (0.5, 0.8), "offset"),                 # around the 2048-position tiles: the first and last tile test every element's range
+    (2049, (0.5, 0.8), "drift"),
+    (4065, (0.0, 0.95), "offset"),
+    (65_536, (0.6, 0.97), "offset"),              # the provisional centre is the mean of the whole column up to here ...
+    (65_537, (0.6, 0.97), "drift"),               # ... and of 64 runs of 1024 rows beyond
+    (300_000, (0.2, 0.9, 0.99), "drift"),         # a start far from where the chain settles: the sampled centre is well off the mean
+    (200_000, (0.999,), "offset"),                # > 2048 lags: the edge sums are fetched again for the column that goes on
+    (1_048_576 + 31, (0.5, 0.9), "trend+offset"),
+])
+def test_initseq_uncentred_vs_oracle(api, oracle_mod, n, rhos, kind):
+    """mcmchip_initseq_uncentred (lag sums about a provisional centre per column, carried over to the mean on the host; the
+    series is not modified) against the oracle on x - mean(x), R/initseq.R:3-4 + initseq.c, to the 1e-10 of the other initseq
+    comparisons; the column means it returns; host and device pointers give the same bits."""
+    import torch
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(n)
+    p = len(rhos)
+    x = np.column_stack([lfilter([1.0], [1.0, -r], rng.standard_normal(n)) for r in rhos])
+    x = x * rng.choice([0.01, 1.0, 30.0], p) + rng.choice([-300.0, 7.0, 1000.0], p) * x.std(axis=0)      # means 7 .. 1000 sd away
+    if kind == "drift":
+        x += 25.0 * x.std(axis=0) * np.exp(-np.arange(n) / (n / 50.0))[:, None]
+    if kind == "trend+offset":
+        x[:, 0] += np.linspace(-0.2, 0.2, n) * x[:, 0].std()
+    xt = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+    keep = xt.clone()
+    got = api.initseq(xt)                                    # resident and not declared centred -> the new entry point
+    assert torch.equal(xt, keep)                             # inputs are never modified
+    mu = x.mean(axis=0)
+    for c in range(p):
+        ref = oracle_mod.initseq(x[:, c] - mu[c])
+        assert len(got[c]["Gamma.pos"]) == len(ref["Gamma.pos"]), (c, len(got[c]["Gamma.pos"]), len(ref["Gamma.pos"]))
+        for key in INITSEQ_KEYS:
+            assert np.max(np.abs(np.asarray(got[c][key]) - np.asarray(ref[key]))) <= 1e-10 * np.max(np.abs(ref[key])), (c, key)
+    cap = max(len(g["Gamma.pos"]) for g in got)
+    rc, n_out, g0, Gp, Gd, Gc, vp, vd, vc, mean = _initseq_uncentred_raw(api, xt.data_ptr(), n, p, 1, cap)
+    assert rc == 0 and np.allclose(mean, mu, rtol=1e-13, atol=0.0)
+    xf = np.asfortranarray(x)                                # the same through a host pointer (staged through HBM): same bits
+    rc, n_out2, g02, Gp2, Gd2, Gc2, vp2, vd2, vc2, mean2 = _initseq_uncentred_raw(api, xf.ctypes.data, n, p, 0, cap)
+    assert rc == 0 and np.array_equal(n_out, n_out2) and np.array_equal(vc, vc2) and np.array_equal(mean, mean2)
+    for c in range(p):
+        assert np.array_equal(Gc[c, :n_out[c]], Gc2[c, :n_out2[c]]) and np.array_equal(Gc[c, :n_out[c]], got[c]["Gamma.con"])
+
+
+def test_initseq_uncentred_many_columns_errors_and_capacity(api, oracle_mod):
+    """300 short columns in one call (stopping lags from 1 to dozens, every column its own centre); the capacity protocol and
+    the finiteness check of mcmchip_initseq (initseq.c:15) carry over; agreement with mcmchip_initseq on the centred series."""
+    import torch
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(77)
+    n, p = 6000, 300
+    rho = rng.uniform(-0.7, 0.97, p)
+    x = np.column_stack([lfilter([1.0], [1.0, -r], rng.standard_normal(n)) for r in rho]) + rng.uniform(-100, 100, p)
+    xt = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+    got = api.initseq(xt)
+    cen = api.initseq(torch.from_numpy(np.ascontiguousarray((x - x.mean(axis=0)).T)).cuda(), centred=True)
+    for c in range(p):
+        assert len(got[c]["Gamma.pos"]) == len(cen[c]["Gamma.pos"])
+        for key in INITSEQ_KEYS:
+            assert np.max(np.abs(np.asarray(got[c][key]) - np.asarray(cen[c][key]))) <= 1e-11 * np.max(np.abs(cen[c][key])), (c, key)
+    for c in (0, 17, 299):
+        ref = oracle_mod.initseq(x[:, c] - x[:, c].mean())
+        assert abs(got[c]["var.con"] - ref["var.con"]) <= 1e-10 * abs(ref["var.con"])
+    # capacity too small: MCMCHIP_ECAP and the lengths needed, as mcmchip_initseq reports them
+    rc, n_out, *_ = _initseq_uncentred_raw(api, xt.data_ptr(), n, p, 1, cap=1)
+    assert rc == abi.ECAP and np.array_equal(n_out, [len(g["Gamma.pos"]) for g in got])
+    # a non-finite element, resident (found on the device) and in host memory (found before the upload)
+    L = api.load_library()
+    xt[5, 4321] = float("inf")
+    rc, *_ = _initseq_uncentred_raw(api, xt.data_ptr(), n, p, 1)
+    assert rc == abi.EINVAL and b"all elements of argument must be finite" in L.mcmchip_last_error()
+    xbad = np.asfortranarray(x)
+    xbad[100, 200] = np.nan
+    rc, *_ = _initseq_uncentred_raw(api, xbad.ctypes.data, n, p, 0)
+    assert rc == abi.EINVAL and b"all elements of argument must be finite" in L.mcmchip_last_error()
+    # tiny series: n = 1 (no lag pair), 2, 3
+    for nn in (1, 2, 3, 5):
+        v = rng.standard_normal((nn, 2)) + 10.0
+        vt = torch.from_numpy(np.ascontiguousarray(v.T)).cuda()
+        a, b = api.initseq(vt), api.initseq(torch.from_numpy(np.ascontiguousarray((v - v.mean(axis=0)).T)).cuda(), centred=True)
+        for c in range(2):
+            assert len(a[c]["Gamma.pos"]) == len(b[c]["Gamma.pos"])
+            assert np.allclose(a[c]["gamma0"], b[c]["gamma0"], rtol=1e-12, atol=1e-15)
+            assert np.allclose(a[c]["Gamma.pos"], b[c]["Gamma.pos"], rtol=1e-10, atol=1e-14)
+
+
 def test_time_sharded_initseq_and_olbm_device_route(api, oracle_mod):
     """mcmc_amd/dist.py with device-resident shards (CUDA tensors, nothing but p and p x p / ncol x nlags doubles on the
     host): ranks emulated in turn without a process group, the all-reduce replaced by a sum over the emulated ranks.

@@ -1,0 +1,13 @@
+"""the C5 block of bench_secondary.py alone (initseq / olbm on the 204.8 GB resident series); usage: python tools/c5_only.py"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from mcmc_amd import api  # noqa: E402
+import bench_secondary  # noqa: E402
+
+api.init()
+print(json.dumps(bench_secondary.run(api, torch, torch.device("cuda:0"), ("c5",)), indent=1))
