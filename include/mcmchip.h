@@ -332,7 +332,7 @@ int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs,
 
 /* initseq of a series that is NOT centred yet: R/initseq.R:3-4 (x - mean(x), then the native call) in one call that reads
  * the series once per round and leaves it as it is -- for a batch resident in HBM centring in place costs a read pass and
- * a read-write pass over the series before the first lag product (C5: 77 ms next to initseq's 73).  The lag sums are taken
+ * a read-write pass over the series before the first lag product (C5: 123 ms next to initseq's 72; this call: 82).  The lag sums are taken
  * about a provisional centre per column (the mean of 64 runs of 1024 rows spread over the column) and carried over to the
  * mean exactly: with z = x - centre, delta = mean(z),
  *     sum_t (z[t] - delta)(z[t+k] - delta) = sum_t z[t] z[t+k] - (len + k) delta^2 + delta (H_k + T_k),

@@ -296,17 +296,23 @@ __global__ __launch_bounds__(256, (AcShape<NACC, FIRST, PAIR>::OCC)) void autoco
 #pragma unroll
                     for (int i = 0; i < SA; i++) P[t + 256 * i] = zx(r[i], 256 * i);
                 }
+                double zt[IS_TILE / 256];
 #pragma unroll
                 for (int i = 0; i < SY; i++) {
                     const double v0 = zy(r[Y0 + 2 * i], 256 * i), v1 = zy(r[Y0 + 2 * i + 1], 256 * i + 1);
                     if constexpr (FIRST) {
                         if (i < SA) P[t + 256 * i] = v0;
-                        if (i < IS_TILE / 256) {                // each position once
-                            ssq = __builtin_fma(v0, v0, ssq);
-                            ssum += v0;
-                        }
+                        if (i < IS_TILE / 256) zt[i] = v0;      // each position once
                     }
                     P[SA * 256 + t + 256 * i] = v0 + v1;
+                }
+                if constexpr (FIRST) {
+                    // sum and sum of squares of the tile's eight values as trees: two dependent chains of eight would sit in
+                    // the way of the loads' consumers
+                    static_assert(IS_TILE / 256 == 8, "the trees below take eight values");
+                    ssum += ((zt[0] + zt[1]) + (zt[2] + zt[3])) + ((zt[4] + zt[5]) + (zt[6] + zt[7]));
+                    ssq += (__builtin_fma(zt[0], zt[0], zt[1] * zt[1]) + __builtin_fma(zt[2], zt[2], zt[3] * zt[3])) +
+                           (__builtin_fma(zt[4], zt[4], zt[5] * zt[5]) + __builtin_fma(zt[6], zt[6], zt[7] * zt[7]));
                 }
             };
             // every element the tile's loads touch lies inside the series (uniform over the workgroup)
