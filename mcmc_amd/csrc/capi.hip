@@ -578,7 +578,7 @@ int mcmchip_metrop(const mcmchip_target *t, const mcmchip_metrop_args *a, mcmchi
         rc = run_metrop_mfma(t, p, dc);
     } else {
         timing_reset("metrop_stream_kernel");
-        rc = launch_metrop_stream(p, s);         // one or more timed launches
+        rc = launch_metrop_stream(p, s, batch.host, dc->side[0], &batch.went_home);         // one or more timed launches
     }
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     rc = check_flag(dc, false);     // synchronises; device buffers are released by the destructors

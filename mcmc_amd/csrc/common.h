@@ -104,6 +104,7 @@ struct DevBuf {
 // hostcopy.hip: pageable host memory <-> HBM; large copies are pipelined through pinned chunks and host threads
 hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipStream_t s);
 hipError_t copy_from_pageable_host(void *dev, const void *host, size_t bytes, hipStream_t s);
+hipError_t copy_rows_to_pageable_host(void *host, const void *dev, size_t nrows, size_t row_bytes, size_t pitch, hipStream_t s);
 
 // bring an input into HBM: either the caller's device pointer as-is, or a staged copy
 struct InBuf {
@@ -137,8 +138,10 @@ struct OutBuf {
         ptr = own.p;
         return e;
     }
+    bool went_home = false;      // the run has copied it back already, piece by piece (metrop_stream.hip)
     hipError_t finish(hipStream_t s)
     {
+        if (went_home) return hipSuccess;
         if (host && ptr && bytes) return copy_to_pageable_host(host, ptr, bytes, s);
         return hipSuccess;
     }

@@ -114,6 +114,74 @@ hipError_t copy_to_pageable_host(void *host, const void *dev, size_t bytes, hipS
     return rc;
 }
 
+// Rows of a pitched device array into the same rows of a pageable host array of the same pitch: row r = row_bytes bytes at
+// offset r * pitch on both sides.  What a launch of a run leaves behind when the results are laid out [chain][batch][nout]
+// and the launch produced batches [b0, b1) of every chain: the part of the result that can go home while the next
+// launch runs (metrop_stream.hip).  A ring chunk takes as many whole rows as fit, packed, from one 2-d DMA; the host
+// threads deal the rows of a chunk out among themselves.  Blocks until the rows have landed; s is idle on return.
+hipError_t copy_rows_to_pageable_host(void *host, const void *dev, size_t nrows, size_t row_bytes, size_t pitch, hipStream_t s)
+{
+    if (!nrows || !row_bytes) return hipSuccess;
+    const char *env = getenv("MCMCHIP_COPY_THREADS");
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    if (row_bytes > HC_CHUNK || (env && atoi(env) == 0) || !ring_ready()) {
+        hipError_t e = hipMemcpy2DAsync(host, pitch, dev, pitch, row_bytes, nrows, hipMemcpyDeviceToHost, s);
+        return e != hipSuccess ? e : hipStreamSynchronize(s);
+    }
+    hipEvent_t ev[HC_NBUF];
+    for (int i = 0; i < HC_NBUF; i++) {
+        hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; j++) (void)hipEventDestroy(ev[j]);
+            return e;
+        }
+    }
+    const size_t R = HC_CHUNK / row_bytes;                  // rows per chunk
+    const long nchunks = (long)((nrows + R - 1) / R);
+    const int T = copy_threads();
+    std::atomic<long> ready{0};
+    std::atomic<bool> stop{false};
+    std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[nchunks]);
+    for (long c = 0; c < nchunks; c++) done[c].store(0, std::memory_order_relaxed);
+    auto chunk_rows = [&](long c) { return (size_t)(c + 1) * R <= nrows ? R : nrows - (size_t)c * R; };
+    auto worker = [&](int t) {
+        for (long c = 0; c < nchunks; c++) {
+            while (ready.load(std::memory_order_acquire) <= c) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const size_t rows = chunk_rows(c);
+            // a thread takes neighbouring rows: the pages (2 MB ones, where the kernel hands them out) of its part of the
+            // destination are first touched by it alone
+            const size_t per = (rows + (size_t)T - 1) / (size_t)T, i0 = (size_t)t * per, i1 = i0 + per < rows ? i0 + per : rows;
+            for (size_t i = i0; i < i1; i++)
+                memcpy((char *)host + ((size_t)c * R + i) * pitch, (const char *)g_ring.buf[c % HC_NBUF] + i * row_bytes, row_bytes);
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(T);
+    for (int t = 0; t < T; t++) pool.emplace_back(worker, t);
+    hipError_t rc = hipSuccess;
+    for (long c = 0; c <= nchunks && rc == hipSuccess; c++) {
+        if (c < nchunks) {
+            if (c >= HC_NBUF)
+                while (done[c - HC_NBUF].load(std::memory_order_acquire) < T) std::this_thread::yield();
+            rc = hipMemcpy2DAsync(g_ring.buf[c % HC_NBUF], row_bytes, (const char *)dev + (size_t)c * R * pitch, pitch, row_bytes,
+                                  chunk_rows(c), hipMemcpyDeviceToHost, s);
+            if (rc == hipSuccess) rc = hipEventRecord(ev[c % HC_NBUF], s);
+        }
+        if (c >= 1 && rc == hipSuccess) {
+            rc = hipEventSynchronize(ev[(c - 1) % HC_NBUF]);
+            if (rc == hipSuccess) ready.store(c, std::memory_order_release);
+        }
+    }
+    if (rc != hipSuccess) stop.store(true, std::memory_order_relaxed);
+    for (auto &th : pool) th.join();
+    for (int i = 0; i < HC_NBUF; i++) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
 // The other direction: pageable host memory into HBM.  One hipMemcpy runs at ~27 GB/s on the box (the runtime stages
 // through its own pinned buffer on one thread); here host threads fill the pinned ring while the DMA engine empties the
 // chunk before.  The source must stay valid until the call returns; on return the copies are enqueued AND complete.

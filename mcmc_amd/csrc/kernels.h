@@ -40,7 +40,11 @@ struct MetropDev {
 };
 
 // metrop_stream.hip: one persistent launch, G lanes per chain, whole nbatch*blen*nspac loop in-kernel
-int launch_metrop_stream(const MetropDev &p, hipStream_t s);
+// batch_home != nullptr: the caller's host array for p.batch ([chain][batch][nout], pageable); a run of several launches
+// whose batch means are large copies them there launch by launch, each copy under the next launch (on `side`), and sets
+// *went_home; otherwise the caller copies at the end
+int launch_metrop_stream(const MetropDev &p, hipStream_t s, void *batch_home = nullptr, hipStream_t side = nullptr,
+                         bool *went_home = nullptr);
 // log density of nchain states (chain-major; temper kinds: (i, theta))
 int launch_logdens_stream(const mcmchip_target *t, const double *states, long nchain, double *out,
                           hipStream_t s);

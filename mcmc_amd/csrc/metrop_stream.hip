@@ -19,6 +19,7 @@
 // scale accumulates column by column in i order (metrop.c:391-399).
 #include "metrop_stream_impl.h"
 #include <stdlib.h>
+#include <chrono>
 
 static int pick_group(long work, long nchain)
 {
@@ -30,7 +31,7 @@ static int pick_group(long work, long nchain)
     return 1;
 }
 
-int launch_metrop_stream(const MetropDev &p, hipStream_t s)
+int launch_metrop_stream(const MetropDev &p, hipStream_t s, void *batch_home, hipStream_t side, bool *went_home)
 {
     const int d = p.d;
     long work = d;
@@ -85,8 +86,50 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
     DevBuf carry;
     long done = 0, last_iters = 0;
     double last_ms = 0.0;
+    // Batch means on their way to pageable host memory, 64 MB and more of them (C2: 1.6 GB behind a 30 ms kernel, 45 ms on
+    // the PCIe link): the run is cut into 4 launches after the calibration launch (more for a run longer than the launch budget) and the batches a launch completed go
+    // home (copy_rows_to_pageable_host, on `side`) while the next launch runs.  In the result's layout
+    // [chain][batch][nout] they are one run of (b1 - b0) * nout doubles per chain.
+    const long per_batch = (long)p.blen * p.nspac;
+    const size_t pitch = (size_t)p.nbatch * p.nout * 8;
+    bool piecewise = batch_home && side && went_home && p.batch && p.nout > 0 && (size_t)p.nchain * pitch >= ((size_t)64 << 20) &&
+                     !getenv("MCMCHIP_NO_PIECEWISE_COPY");
+    long seg_iters = 0;                       // launch length while copying piecewise
+    long home_b = 0;                          // batches [0, home_b) are in the caller's array or on their way
+    // pieces whose launches are queued but whose copies are not: up to AHEAD launches (one launch budget in all, see below) are
+    // queued behind the piece being copied, so the device does not wait for the host between launches
+    constexpr int AHEAD = 8;
+    struct Piece { long b0, b1; hipEvent_t ev; };
+    Piece pend[AHEAD + 1];
+    int npend = 0;
+    hipEvent_t ev[AHEAD + 1] = {};
+    int cur = 0;
+    const bool trace = getenv("MCMCHIP_TRACE") != nullptr;
+    auto send_oldest = [&]() -> int {
+        const Piece pc = pend[0];
+        for (int i = 1; i < npend; i++) pend[i - 1] = pend[i];
+        npend--;
+        if (pc.b1 <= pc.b0) return MCMCHIP_OK;
+        HIP_TRY(hipStreamWaitEvent(side, pc.ev, 0));
+        const auto t0 = std::chrono::steady_clock::now();
+        if (trace) (void)hipEventSynchronize(pc.ev);
+        const auto t1 = std::chrono::steady_clock::now();
+        HIP_TRY(copy_rows_to_pageable_host((char *)batch_home + (size_t)pc.b0 * p.nout * 8, (const char *)p.batch + (size_t)pc.b0 * p.nout * 8,
+                                           (size_t)p.nchain, (size_t)(pc.b1 - pc.b0) * p.nout * 8, pitch, side));
+        if (trace)
+            fprintf(stderr, "[metrop_stream] piece of %.1f MB: waited %.2f ms for its launch, copy %.2f ms\n",
+                    (double)p.nchain * (double)(pc.b1 - pc.b0) * p.nout * 8 / 1e6, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+        return MCMCHIP_OK;
+    };
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard() { for (int i = 0; i <= AHEAD; i++) if (e[i]) (void)hipEventDestroy(e[i]); }
+    } guard{ev};
     while (done < niter) {
-        const long n = next_launch_iters(niter - done, last_iters, last_ms, 1);
+        long n;
+        if (piecewise && seg_iters > 0) n = seg_iters < niter - done ? seg_iters : niter - done;
+        else n = next_launch_iters(niter - done, last_iters, last_ms, 1);
         q.l_begin = done;
         q.l_end = done + n;
         q.resume = done > 0;
@@ -105,11 +148,42 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s)
         timing_end(s);
         if (rc) return rc;
         done += n;
+        if (piecewise && seg_iters > 0) {
+            // this launch is queued: its batches join the pieces waiting, the oldest goes home once AHEAD launches are behind it
+            if (!ev[cur]) HIP_TRY(hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev[cur], s));
+            pend[npend++] = Piece{home_b, done / per_batch, ev[cur]};
+            home_b = done / per_batch;
+            cur = (cur + 1) % (AHEAD + 1);
+            if (npend > AHEAD)
+                if (int crc = send_oldest()) return crc;
+            if (done < niter)
+                if (int irc = poll_interrupt()) return irc;
+            continue;
+        }
         if (done < niter) {
             last_ms = timing_last_ms();          // waits for the launch: the host poll point
             last_iters = n;
             if (int irc = poll_interrupt()) return irc;
+            if (piecewise) {
+                // after the calibration launch: a quarter of the rest per launch, whole batches, within the launch budget,
+                // rows of at least 1 KB per chain (else the copy stays where it was, behind the run)
+                const long budget = next_launch_iters(1L << 60, last_iters, last_ms, 1);        // iterations of one launch budget
+                // (4 pieces: a launch more costs 0.8 ms at C2 -- table and data back into LDS -- and what there is to hide, the
+                // copy less the page faults of a fresh destination, which all fall into the first piece, is 4 ms per 200 MB)
+                long pieces = 4;
+                if (const char *e = getenv("MCMCHIP_PIECES")) pieces = atol(e) > 0 ? atol(e) : 4;      // experiments
+                long want = ((niter - done + pieces - 1) / pieces + per_batch - 1) / per_batch * per_batch;
+                if (want > budget / AHEAD) want = budget / AHEAD / per_batch * per_batch;     // all the queued launches within one budget
+                if (want >= per_batch && (size_t)(want / per_batch) * p.nout * 8 >= 1024) seg_iters = want;
+                else piecewise = false;
+            }
         }
+    }
+    if (piecewise && seg_iters > 0) {
+        while (npend > 0)
+            if (int crc = send_oldest()) return crc;
+        *went_home = true;
     }
     if (carry.p) HIP_TRY(hipStreamSynchronize(s));      // the carry buffer is released on return
     return MCMCHIP_OK;

@@ -139,15 +139,19 @@ def test_device_pointer_inputs_are_validated(api):
     assert rc == abi.EINVAL and b"all elements of argument must be finite" in L.mcmchip_last_error()
 
 
-@pytest.mark.parametrize("Cn,nbatch,thread_counts", [
-    (4099, 523, (None, "1", "0")),        # 85.75 MB of batch means: 5 whole 16 MB chunks and a ragged one
+@pytest.mark.parametrize("Cn,nbatch,blen,nspac,thread_counts", [
+    (4099, 523, 1, 1, (None, "1", "0")),        # 85.75 MB of batch means: 5 whole 16 MB chunks and a ragged one
     # the last chunk is 16 * 4096 * 242 + 8 bytes: with 16 copy threads floor(len / T) is a whole number of pages and
     # T slices of that size stop 8 bytes short of the chunk (the last double was never copied before the slice size
     # became ceil(len / T))
-    (4191, 595, ("16", "12", "32")),
+    (4191, 595, 1, 1, ("16", "12", "32")),
+    # batches of 3 x 2 iterations: the 256-iteration calibration launch and the launches after it end inside a batch, and the
+    # pieces that go home under the next launch (metrop_stream.hip) are whole batches only; "piecewise off": the copy behind the run
+    (4099, 523, 3, 2, (None, "0", "piecewise off")),
 ])
-def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api, monkeypatch, Cn, nbatch, thread_counts):
-    """Results of 64 MB and more go back to pageable host memory through hostcopy.hip (pinned ring + host threads).
+def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api, monkeypatch, Cn, nbatch, blen, nspac, thread_counts):
+    """Results of 64 MB and more go back to pageable host memory through hostcopy.hip (pinned ring + host threads), the
+    batch means of a run of several launches piece by piece, each piece under the launch after it.
     The same Philox run with device_ptrs = 1 leaves them in HBM: both must hold the same bits, also when the last chunk
     is ragged, with one copy thread, with more threads than the default 8, and with the plain copy
     (MCMCHIP_COPY_THREADS = 0)."""
@@ -164,19 +168,23 @@ def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api
     shapes = ((Cn,), (Cn, nbatch, d), (Cn, d), (Cn, nbatch))
     init_d = torch.from_numpy(init_h).to(dev)
     outs_d = [torch.empty(s_, dtype=torch.float64, device=dev) for s_ in shapes]
-    args = abi.MetropArgs(Cn, nbatch, 1, 1, init_d.data_ptr(), abi.SCALE_CONSTANT, scale.ctypes.data, abi.OUT_IDENTITY, None,
+    args = abi.MetropArgs(Cn, nbatch, blen, nspac, init_d.data_ptr(), abi.SCALE_CONSTANT, scale.ctypes.data, abi.OUT_IDENTITY, None,
                           abi.RNG_PHILOX, None, None, 7, 0, 0, 0, 1, abi.PATH_STREAM)
     out = abi.MetropOut(*[t.data_ptr() for t in outs_d], None, None, None, None, None, None, 0, 0, 0)
     assert L.mcmchip_metrop(tg.handle, C.addressof(args), C.addressof(out)) == 0, L.mcmchip_last_error()
     want = [t.cpu().numpy() for t in outs_d]
     assert want[1].nbytes >= 64 << 20
     for threads in thread_counts:
+        monkeypatch.delenv("MCMCHIP_NO_PIECEWISE_COPY", raising=False)
         if threads is None:
             monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
+        elif threads == "piecewise off":
+            monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
+            monkeypatch.setenv("MCMCHIP_NO_PIECEWISE_COPY", "1")
         else:
             monkeypatch.setenv("MCMCHIP_COPY_THREADS", threads)
         outs_h = [np.full(s_, np.nan) for s_ in shapes]
-        args_h = abi.MetropArgs(Cn, nbatch, 1, 1, init_h.ctypes.data, abi.SCALE_CONSTANT, scale.ctypes.data, abi.OUT_IDENTITY,
+        args_h = abi.MetropArgs(Cn, nbatch, blen, nspac, init_h.ctypes.data, abi.SCALE_CONSTANT, scale.ctypes.data, abi.OUT_IDENTITY,
                                 None, abi.RNG_PHILOX, None, None, 7, 0, 0, 0, 0, abi.PATH_STREAM)
         out_h = abi.MetropOut(*[a_.ctypes.data for a_ in outs_h], None, None, None, None, None, None, 0, 0, 0)
         assert L.mcmchip_metrop(tg.handle, C.addressof(args_h), C.addressof(out_h)) == 0, L.mcmchip_last_error()
