@@ -20,7 +20,7 @@ with open(out + '/summary.txt', 'w') as w:
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(g[0])):
         if r['Counter_Name'] == 'FETCH_SIZE' and 'autocov_kernel' in r['Kernel_Name']:
-            k = 'CENTRE' if ('true, true>' in r['Kernel_Name'] and 'true, true, true>' in r['Kernel_Name']) or 'false, true, true>' in r['Kernel_Name'] else 'plain'
+            k = 'CENTRE' if ', true>(' in r['Kernel_Name'] else 'plain'        # autocov_kernel<NACC, FIRST, PAIR, CENTRE>
             agg[k][0] += 1
             agg[k][1] += float(r['Counter_Value']) * 2048        # gfx950: FETCH_SIZE counts 2 KB units (MI355X_MICROARCH.md)
     w.write("\nHBM fetch bytes of autocov_kernel launches (FETCH_SIZE x 2048 B), summed over the two calls of each kind:\n")
