@@ -96,9 +96,10 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s, void *batch_home, hi
                      !getenv("MCMCHIP_NO_PIECEWISE_COPY");
     long seg_iters = 0;                       // launch length while copying piecewise
     long home_b = 0;                          // batches [0, home_b) are in the caller's array or on their way
-    // pieces whose launches are queued but whose copies are not: up to AHEAD launches (one launch budget in all, see below) are
-    // queued behind the piece being copied, so the device does not wait for the host between launches
+    // pieces whose launches are queued but whose copies are not: up to `queue_ahead` <= AHEAD launches (one launch budget in all, see
+    // below) are queued behind the piece being copied, so the device does not wait for the host between launches
     constexpr int AHEAD = 8;
+    int queue_ahead = 1;
     struct Piece { long b0, b1; hipEvent_t ev; };
     Piece pend[AHEAD + 1];
     int npend = 0;
@@ -155,7 +156,7 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s, void *batch_home, hi
             pend[npend++] = Piece{home_b, done / per_batch, ev[cur]};
             home_b = done / per_batch;
             cur = (cur + 1) % (AHEAD + 1);
-            if (npend > AHEAD)
+            if (npend > queue_ahead)
                 if (int crc = send_oldest()) return crc;
             if (done < niter)
                 if (int irc = poll_interrupt()) return irc;
@@ -166,17 +167,20 @@ int launch_metrop_stream(const MetropDev &p, hipStream_t s, void *batch_home, hi
             last_iters = n;
             if (int irc = poll_interrupt()) return irc;
             if (piecewise) {
-                // after the calibration launch: a quarter of the rest per launch, whole batches, within the launch budget,
-                // rows of at least 1 KB per chain (else the copy stays where it was, behind the run)
+                // after the calibration launch: a quarter of the rest per launch, whole batches, at most one launch budget (a
+                // long run keeps its launches as long as they were: each costs 0.8 ms at C2), as many launches queued ahead
+                // of the copy as fit one budget; rows of at least 1 KB per chain (else the copy stays behind the run)
                 const long budget = next_launch_iters(1L << 60, last_iters, last_ms, 1);        // iterations of one launch budget
                 // (4 pieces: a launch more costs 0.8 ms at C2 -- table and data back into LDS -- and what there is to hide, the
                 // copy less the page faults of a fresh destination, which all fall into the first piece, is 4 ms per 200 MB)
                 long pieces = 4;
                 if (const char *e = getenv("MCMCHIP_PIECES")) pieces = atol(e) > 0 ? atol(e) : 4;      // experiments
                 long want = ((niter - done + pieces - 1) / pieces + per_batch - 1) / per_batch * per_batch;
-                if (want > budget / AHEAD) want = budget / AHEAD / per_batch * per_batch;     // all the queued launches within one budget
-                if (want >= per_batch && (size_t)(want / per_batch) * p.nout * 8 >= 1024) seg_iters = want;
-                else piecewise = false;
+                if (want > budget) want = budget / per_batch * per_batch;
+                if (want >= per_batch && (size_t)(want / per_batch) * p.nout * 8 >= 1024) {
+                    seg_iters = want;
+                    queue_ahead = (int)(budget / want < 1 ? 1 : (budget / want > AHEAD ? AHEAD : budget / want));
+                } else piecewise = false;
             }
         }
     }

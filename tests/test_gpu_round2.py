@@ -148,9 +148,9 @@ def test_device_pointer_inputs_are_validated(api):
     # batches of 3 x 2 iterations: the 256-iteration calibration launch and the launches after it end inside a batch, and the
     # pieces that go home under the next launch (metrop_stream.hip) are whole batches only; "piecewise off": the copy behind the run
     (4099, 523, 3, 2, (None, "0", "piecewise off")),
-    # launches capped at 240 iterations: the pieces are 30 iterations each, ten of them after the first launch -- more than the
-    # launches the run queues ahead of the copy, so the events behind them are reused
-    (4099, 523, 1, 1, ("limit 240",)),
+    # launches capped at 40 iterations: thirteen pieces after the first launch, one launch queued ahead of each copy -- more
+    # pieces than the run keeps events for, so the events are reused; capped at 240: four pieces of 71 iterations, three queued ahead
+    (4099, 523, 1, 1, ("limit 40", "limit 240")),
 ])
 def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api, monkeypatch, Cn, nbatch, blen, nspac, thread_counts):
     """Results of 64 MB and more go back to pageable host memory through hostcopy.hip (pinned ring + host threads), the
@@ -184,9 +184,9 @@ def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api
         elif threads == "piecewise off":
             monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
             monkeypatch.setenv("MCMCHIP_NO_PIECEWISE_COPY", "1")
-        elif threads == "limit 240":
+        elif threads.startswith("limit "):
             monkeypatch.delenv("MCMCHIP_COPY_THREADS", raising=False)
-            api.set_launch_limit(max_iters=240)
+            api.set_launch_limit(max_iters=int(threads.split()[1]))
         else:
             monkeypatch.setenv("MCMCHIP_COPY_THREADS", threads)
         outs_h = [np.full(s_, np.nan) for s_ in shapes]
@@ -195,8 +195,10 @@ def test_large_host_results_take_the_pipelined_copy_and_match_device_results(api
         out_h = abi.MetropOut(*[a_.ctypes.data for a_ in outs_h], None, None, None, None, None, None, 0, 0, 0)
         try:
             assert L.mcmchip_metrop(tg.handle, C.addressof(args_h), C.addressof(out_h)) == 0, L.mcmchip_last_error()
+            if threads == "limit 40":
+                assert api.last_kernel_time()[2] == 14        # 40 iterations, twelve launches of 40, one of 3
             if threads == "limit 240":
-                assert api.last_kernel_time()[2] == 11        # 240 iterations, nine launches of 30, one of 13
+                assert api.last_kernel_time()[2] == 5         # 240 iterations, three launches of 71, one of 70
         finally:
             api.set_launch_limit()
         for got, ref in zip(outs_h, want):
