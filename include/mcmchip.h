@@ -332,11 +332,11 @@ int mcmchip_initseq(const double *x, int64_t len, int64_t ncol, int device_ptrs,
 
 /* initseq of a series that is NOT centred yet: R/initseq.R:3-4 (x - mean(x), then the native call) in one call that reads
  * the series once per round and leaves it as it is -- for a batch resident in HBM centring in place costs a read pass and
- * a read-write pass over the series before the first lag product (C5: 123 ms next to initseq's 72; this call: 82).  The lag sums are taken
+ * a read-write pass over the series before the first lag product (C5: 123 ms next to initseq's 73; this call: 80).  The lag sums are taken
  * about a provisional centre per column (the mean of 64 runs of 1024 rows spread over the column) and carried over to the
  * mean exactly: with z = x - centre, delta = mean(z),
  *     sum_t (z[t] - delta)(z[t+k] - delta) = sum_t z[t] z[t+k] - (len + k) delta^2 + delta (H_k + T_k),
- * H_k / T_k the sums of the first / last k values of z (a few thousand rows per column, summed on the host).  Same
+ * H_k / T_k the sums of the first / last k values of z (a few thousand rows per column, gathered on the device, summed on the host).  Same
  * arguments, results and errors as mcmchip_initseq; `mean` (host, ncol doubles, or NULL) receives the column means.
  * Results agree with mcmchip_initseq on the centred series to rounding (~1e-13 relative; the tests hold it to the 1e-10
  * of the oracle comparison). */

@@ -63,6 +63,18 @@ __global__ __launch_bounds__(256) void sample_centre_kernel(const double *__rest
     if (threadIdx.x == 0) centre[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) / (double)cnt;
 }
 
+// the first and the last K rows of every column side by side, out[c][0 .. K) and out[c][K .. 2K): one contiguous copy to the
+// host instead of two pitched ones of ncol short rows each (which took 4 ms of the C5 call)
+__global__ __launch_bounds__(256) void edge_gather_kernel(const double *__restrict__ x, long len, long K, double *__restrict__ out)
+{
+    const double *xc = x + (size_t)blockIdx.x * len;
+    double *o = out + (size_t)blockIdx.x * 2 * K;
+    for (long k = threadIdx.x; k < K; k += 256) {
+        o[k] = xc[k];
+        o[K + k] = xc[len - K + k];
+    }
+}
+
 // Host post-processing of one column's Gamma sequence (a few hundred numbers).  What initseq.c:49-105 returns:
 //   Gamma.pos  the sequence as computed (truncated at the first negative term, which is stored as 0),
 //   Gamma.dec  its greatest non-increasing minorant = running minimum,
@@ -320,8 +332,8 @@ double predict_pairs(const double *G, long m, long len)
 //     sum_{t < len-k} w[t] w[t+k] = sum_{t < len-k} z[t] z[t+k] - delta (2 S - H_k - T_k) + (len - k) delta^2
 //                                 = sum_{t < len-k} z[t] z[t+k] - (len + k) delta^2 + delta (H_k + T_k),
 // H_k (T_k) the sum of the first (last) k values of z.  This holds H_k + T_k per column for k <= K, from the first and last
-// K rows of the series copied to the host (two strided copies for all columns; a column that goes beyond K lags -- rare:
-// K starts at 2048 -- has its edges fetched again, alone).
+// K rows of the series copied to the host (gathered on the device for all columns, one copy; a column that goes beyond K
+// lags -- rare: K starts at 2048 -- has its edges fetched again, alone).
 struct EdgeSums {
     long K = 0;
     std::vector<std::vector<double>> ht;          // [column][k], k = 0 .. K (of the columns asked for last)
@@ -338,12 +350,14 @@ struct EdgeSums {
         K = k;
         if (all) {
             ht.assign((size_t)ncol, std::vector<double>());
-            head.resize((size_t)ncol * K);
-            tail.resize((size_t)ncol * K);
-            HIP_TRY(hipMemcpy2DAsync(head.data(), (size_t)K * 8, x, (size_t)len * 8, (size_t)K * 8, (size_t)ncol, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpy2DAsync(tail.data(), (size_t)K * 8, x + (len - K), (size_t)len * 8, (size_t)K * 8, (size_t)ncol, hipMemcpyDeviceToHost, s));
+            head.resize((size_t)ncol * 2 * K);
+            DevBuf gathered;
+            HIP_TRY(gathered.alloc((size_t)ncol * 2 * K * 8));
+            hipLaunchKernelGGL(edge_gather_kernel, dim3((unsigned)ncol), dim3(256), 0, s, x, len, K, gathered.as<double>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(head.data(), gathered.p, (size_t)ncol * 2 * K * 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            for (long c = 0; c < ncol; c++) fill(c, head.data() + (size_t)c * K, tail.data() + (size_t)c * K, cen[(size_t)c]);
+            for (long c = 0; c < ncol; c++) fill(c, head.data() + (size_t)c * 2 * K, head.data() + (size_t)c * 2 * K + K, cen[(size_t)c]);
         } else {
             head.resize((size_t)K);
             tail.resize((size_t)K);
