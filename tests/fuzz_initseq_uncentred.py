@@ -27,7 +27,9 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     kind = it % 4
     if kind == 2 and n > 100_000:       # a trend keeps the stop rule away for ~n / 4 lags: beyond the CPU oracle's reach
         kind = 0
-    rho = rng.uniform(-0.6, 0.99 if n >= 100_000 else 0.95, p)
+    if n >= 2_000_000:                  # the CPU oracle is O(n x lags): keep the stopping lag of the longest series in the hundreds
+        kind = 0
+    rho = rng.uniform(-0.6, 0.9 if n >= 2_000_000 else (0.99 if n >= 100_000 else 0.95), p)
     x = np.column_stack([lfilter([1.0], [1.0, -r], rng.standard_normal(n)) for r in rho])
     off = rng.choice([0.0, 1.0, -30.0, 1e3, 1e6], p)
     x = x * rng.choice([1e-3, 1.0, 40.0], p) + off
