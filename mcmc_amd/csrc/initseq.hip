@@ -343,8 +343,7 @@ struct EdgeSums {
         if (need > len) need = len;
         if (need <= K) return MCMCHIP_OK;
         const bool all = K == 0;
-        // first for all columns at once: at most 2048 rows, and at most 2 x 256 MB of host memory however many columns
-        long k = K == 0 ? std::max(64L, std::min(2048L, (32L << 20) / ncol)) : 2 * K;
+        long k = K == 0 ? first_rows(len, ncol) : 2 * K;
         if (k < need) k = need;
         if (k > len) k = len;
         K = k;
@@ -369,6 +368,18 @@ struct EdgeSums {
             }
         }
         return MCMCHIP_OK;
+    }
+    // the edges of all columns as edge_gather_kernel left them ([column][2 k]: first k rows, last k rows), already on the host
+    void take_all(const double *gathered, long ncol, long k, const std::vector<double> &cen)
+    {
+        K = k;
+        ht.assign((size_t)ncol, std::vector<double>());
+        for (long c = 0; c < ncol; c++) fill(c, gathered + (size_t)c * 2 * K, gathered + (size_t)c * 2 * K + K, cen[(size_t)c]);
+    }
+    static long first_rows(long len, long ncol)       // at most 2048 rows, and at most 2 x 256 MB of host memory however many columns
+    {
+        const long k = std::max(64L, std::min(2048L, (32L << 20) / ncol));
+        return k < len ? k : len;
     }
     void fill(long c, const double *h, const double *t, double centre)
     {
@@ -432,13 +443,20 @@ int run_initseq(const double *x, long len, long ncol, long cap, long *n_out, dou
     const double *centre = nullptr;
     if (about_mean) {
         if (ncol > 0x7fffffffL) return set_error(MCMCHIP_EINVAL, "too many columns");
-        HIP_TRY(dcentre.alloc((size_t)ncol * 8));
+        // one buffer, two small kernels, one copy, one wait: the centres, then the first / last rows of every column
+        const long k0 = EdgeSums::first_rows(len, ncol);
+        const size_t nd = (size_t)ncol * (1 + 2 * (size_t)k0);
+        HIP_TRY(dcentre.alloc(nd * 8));
         hipLaunchKernelGGL(sample_centre_kernel, dim3((unsigned)ncol), dim3(256), 0, dc->stream, x, len, dcentre.as<double>());
         HIP_TRY(hipGetLastError());
-        cen.resize((size_t)ncol);
-        delta.assign((size_t)ncol, 0.0);
-        HIP_TRY(hipMemcpyAsync(cen.data(), dcentre.p, (size_t)ncol * 8, hipMemcpyDeviceToHost, dc->stream));
+        hipLaunchKernelGGL(edge_gather_kernel, dim3((unsigned)ncol), dim3(256), 0, dc->stream, x, len, k0, dcentre.as<double>() + ncol);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> up(nd);
+        HIP_TRY(hipMemcpyAsync(up.data(), dcentre.p, nd * 8, hipMemcpyDeviceToHost, dc->stream));
         HIP_TRY(hipStreamSynchronize(dc->stream));
+        cen.assign(up.begin(), up.begin() + ncol);
+        delta.assign((size_t)ncol, 0.0);
+        edges.take_all(up.data() + ncol, ncol, k0, cen);
         centre = dcentre.as<double>();
     }
     if (half == 0) active.clear();
